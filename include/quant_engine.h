@@ -1,0 +1,152 @@
+/*
+ * quant_engine.h -- C ABI of the MI355X (gfx950) quantized-conv2d engine.
+ *
+ * This is the drop-in boundary for the reference's `engine.kernels` extension
+ * (JingInAI/Quantize, pybind module `quant_engine`, engine/kernels/pybind.cpp:7-17).
+ * Every entry point takes plain device pointers, sizes and a HIP stream; no torch
+ * types appear here.  The torch-facing `quant_engine` Python module
+ * (quantize_amd/csrc/torch_binding.cpp) is a thin layer over these calls that
+ * reproduces the reference's argument checks, allocation and error class.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless stated otherwise;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *     every call is asynchronous on that stream and performs no host sync,
+ *     allocation or free (graph-capturable);
+ *   - return value: QE_OK or a QE_ERR_* code; qe_error_string() gives the text,
+ *     which for the reference's own checks is the reference's message verbatim;
+ *   - packed tensor format (reference: engine/kernels/tpack/tpack.cu:50-81,
+ *     tpack.h:14-15): element i of an n_bits-wide tensor occupies bits
+ *     [i*n_bits, (i+1)*n_bits) of a little-endian bit stream, stored value =
+ *     q + (sign ? 2^(n_bits-1) : 0); the stream is ceil(n*n_bits/8) bytes, no
+ *     padding between elements, rows or channels.
+ */
+#ifndef QUANT_ENGINE_H
+#define QUANT_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *qe_stream_t; /* hipStream_t */
+
+enum qe_status {
+    QE_OK = 0,
+    QE_ERR_NBITS = 1,       /* "n_bits must be in the range (0, 8]"  tpack.cu:13 */
+    QE_ERR_RANGE = 2,       /* "The input tensor is out of range."   tpack.cu:14 (reported through `status`, see qe_tpack) */
+    QE_ERR_DTYPE = 3,       /* dtype code not in enum qe_dtype */
+    QE_ERR_ARG = 4,         /* null pointer / negative size / inconsistent shape */
+    QE_ERR_HIP = 5,         /* a HIP runtime call failed; see qe_last_hip_error() */
+    QE_ERR_WORKSPACE = 6,   /* workspace too small */
+    QE_ERR_UNSUPPORTED = 7  /* shape outside what the kernels index */
+};
+
+/* Input element types accepted by qe_tpack: the set the reference dispatches on
+ * (AT_DISPATCH_ALL_TYPES_AND(Half), tpack.cu:120). */
+enum qe_dtype {
+    QE_U8 = 0, QE_I8 = 1, QE_I16 = 2, QE_I32 = 3, QE_I64 = 4,
+    QE_F16 = 5, QE_F32 = 6, QE_F64 = 7
+};
+
+const char *qe_error_string(int status);
+/* hipError_t of the last failing HIP call made by this library on this thread (0 = none). */
+int qe_last_hip_error(void);
+/* Library version, and the gfx target the device code was built for ("gfx950"). */
+const char *qe_version(void);
+const char *qe_target_arch(void);
+
+/* ceil(n_elements * n_bits / 8): size of the packed byte stream (tpack.cu:224). */
+int64_t qe_packed_nbytes(int64_t n_elements, int n_bits);
+
+/* ---------------------------------------------------------------------------
+ * qe_tpack -- replaces tpack()/tpack_cuda()/tpack_cuda_kernel
+ *   reference: engine/kernels/tpack/tpack.cu:203-255, :96-128, :30-84.
+ * x        n elements of `dtype`, contiguous.
+ * out      qe_packed_nbytes(n, n_bits) bytes; EVERY byte is written (no
+ *          pre-zeroing needed, unlike tpack.cu:225).
+ * status   optional device int32[1], must be zero on entry; bit 0 is set when any
+ *          element fails the reference's range check (tpack.cu:211-215: value,
+ *          as float, outside [-2^(b-1), 2^(b-1)-1] (sign) or [0, 2^b-1], or NaN).
+ *          The caller reads it back to raise "The input tensor is out of
+ *          range."; `out` is unspecified in that case (the reference raises
+ *          before packing).
+ * ------------------------------------------------------------------------- */
+int qe_tpack(const void *x, int dtype, int64_t n, int n_bits, int sign,
+             uint8_t *out, int32_t *status, qe_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * qe_tunpack -- replaces tunpack()/tunpack_cuda()/tunpack_cuda_kernel
+ *   reference: engine/kernels/tpack/tpack.cu:429-476, :327-359, :267-315.
+ * packed   qe_packed_nbytes(n, n_bits) bytes.
+ * out      n bytes: int8 when sign, uint8 otherwise (tpack.cu:452-455).
+ * ------------------------------------------------------------------------- */
+int qe_tunpack(const uint8_t *packed, int64_t n, int n_bits, int sign,
+               void *out, qe_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Convolution problem description shared by the two conv entry points.
+ * Shapes follow the reference's host code: square stride/padding, no dilation,
+ * no groups (functions/quantconv2d.cu:198-211).  OH/OW are derived:
+ * OH = (H + 2*padding - KH)/stride + 1.
+ * ------------------------------------------------------------------------- */
+typedef struct qe_conv_shape {
+    int32_t N, IC, H, W;     /* input  (N, IC, H, W)   NCHW */
+    int32_t OC, KH, KW;      /* weight (OC, IC, KH, KW) OIHW */
+    int32_t stride, padding;
+} qe_conv_shape;
+
+/* Quantisation parameters of one packed operand.
+ * scale/zero: device fp32 arrays of `n_param` elements.  n_param == 1 means per
+ * tensor (the reference's `numel() == 1` test, quantconv2d.cu:238,244);
+ * otherwise activations index by INPUT channel (quantconv2d.cu:115) and weights
+ * by OUTPUT channel (quantconv2d.cu:130).  Dequantisation follows the kernel
+ * convention (q - zero) * scale (quantconv2d.cu:113-115,128-130). */
+typedef struct qe_qparam {
+    const uint8_t *data;   /* packed bit stream */
+    int32_t n_bits;        /* 1..8  (des[0]) */
+    int32_t sign;          /* 0/1   (des[1]) */
+    const float *scale;
+    const float *zero;
+    int32_t n_param;
+} qe_qparam;
+
+/* Bytes of scratch qe_quantconv2d needs for this problem (0 is possible).
+ * The scratch holds the re-laid-out int8 weights and per-channel epilogue
+ * constants of the MFMA path; contents are dead after the call returns to the
+ * stream order (i.e. may be reused by the next call on the same stream). */
+size_t qe_quantconv2d_workspace_bytes(const qe_conv_shape *shape, int x_bits, int w_bits);
+
+/* ---------------------------------------------------------------------------
+ * qe_quantconv2d -- replaces quantconv2d()/quantconv2d_cuda_kernel
+ *   reference: engine/kernels/functions/quantconv2d.cu:164-264, :49-142.
+ * out[n,oc,oh,ow] = bias[oc] + sum over in-bounds taps (ic,kh,kw) of
+ *     ((qx - zx) * sx) * ((qw - zw) * sw)          (fp32 result, NCHW, contiguous)
+ * x, w     packed operands (see qe_qparam); x holds N*IC*H*W elements, w holds
+ *          OC*IC*KH*KW elements.
+ * bias     fp32[OC] or NULL.
+ * out      fp32[N*OC*OH*OW]; every element is written.
+ * workspace/workspace_bytes  scratch of at least qe_quantconv2d_workspace_bytes().
+ * ------------------------------------------------------------------------- */
+int qe_quantconv2d(const qe_qparam *x, const qe_qparam *w, const float *bias,
+                   const qe_conv_shape *shape, float *out,
+                   void *workspace, size_t workspace_bytes, qe_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * qe_quantconv2d_float_input -- replaces quantconv2d_float_input()/..._cuda
+ *   reference: engine/kernels/functions/quantconv2d_float_input.cu:140-220, :45-121.
+ * x        fp32[N*IC*H*W], NCHW contiguous.
+ * ------------------------------------------------------------------------- */
+int qe_quantconv2d_float_input(const float *x, const qe_qparam *w, const float *bias,
+                               const qe_conv_shape *shape, float *out, qe_stream_t stream);
+
+/* Which kernel family qe_quantconv2d will pick for a problem (for tests, bench
+ * and profiles): 0 = generic fp32 direct convolution, 1 = int8 MFMA implicit GEMM. */
+int qe_quantconv2d_path(const qe_conv_shape *shape, const qe_qparam *x, const qe_qparam *w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUANT_ENGINE_H */

@@ -1,0 +1,93 @@
+"""Build the native parts of quantize_amd in-tree.
+
+  quantize_amd/_ext/libqe_hip.so                     hipcc, --offload-arch=gfx950:
+                                                     HIP kernels + the C ABI of include/quant_engine.h
+  quantize_amd/_ext/quant_engine.cpython-*.so        g++: the torch-facing pybind module (csrc/torch_binding.cpp),
+                                                     linked against libqe_hip.so ($ORIGIN rpath)
+
+hipcc cross-compiles gfx950 without a GPU, so this runs in the CPU-only build container;
+the products are git-ignored and travel to the GPU box with the gpurun snapshot.
+Run as `python -m quantize_amd.build [--force]`.
+"""
+import os
+import subprocess
+import sys
+import sysconfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+EXT_DIR = os.path.join(_HERE, "_ext")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+
+HIP_SOURCES = ["qe_api.hip", "qe_tpack.hip", "qe_conv_generic.hip", "qe_conv_mfma.hip"]
+HIP_HEADERS = ["qe_common.h", os.path.join(INCLUDE, "quant_engine.h")]
+ARCH = "gfx950"
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def lib_path():
+    return os.path.join(EXT_DIR, "libqe_hip.so")
+
+
+def module_path():
+    suffix = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
+    return os.path.join(EXT_DIR, "quant_engine" + suffix)
+
+
+def build_hip(force=False, verbose=False):
+    os.makedirs(EXT_DIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
+    out = lib_path()
+    if not force and not _newer(out, deps):
+        return out
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wall", "-Wno-unused-function", "-I", INCLUDE, "-o", out] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
+def build_torch_module(force=False, verbose=False):
+    import torch
+    from torch.utils import cpp_extension
+
+    os.makedirs(EXT_DIR, exist_ok=True)
+    src = os.path.join(CSRC, "torch_binding.cpp")
+    out = module_path()
+    if not force and not _newer(out, [src, os.path.join(INCLUDE, "quant_engine.h"), lib_path()]):
+        return out
+    incs = cpp_extension.include_paths("cuda") + [sysconfig.get_paths()["include"], INCLUDE]
+    torch_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall",
+           "-Wno-unused-function", "-Wno-deprecated-declarations",
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DHIPBLAS_V2",
+           "-DTORCH_EXTENSION_NAME=quant_engine", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    for i in incs:
+        cmd += ["-isystem", i]
+    cmd += [src, "-o", out, "-L", EXT_DIR, "-lqe_hip", "-L", torch_lib,
+            "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python",
+            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + torch_lib]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
+def build_all(force=False, verbose=False):
+    return build_hip(force, verbose), build_torch_module(force, verbose)
+
+
+if __name__ == "__main__":
+    force = "--force" in sys.argv
+    for p in build_all(force=force, verbose=True):
+        print("built", p)

@@ -1,0 +1,94 @@
+// qe_api.hip -- C-ABI entry points that are not tied to one kernel file:
+// error strings, version, and the conv dispatch (generic fp32 vs int8 MFMA).
+#include "qe_common.h"
+
+namespace qe {
+
+thread_local int g_last_hip_error = 0;
+
+int launch_conv_generic(bool packed_in, const void *x, const qe_qparam *xq, const qe_qparam *w,
+                        const float *bias, const qe_conv_shape *sh, float *out, hipStream_t s);
+
+// qe_conv_mfma.hip
+bool mfma_conv_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w);
+size_t mfma_conv_workspace_bytes(const qe_conv_shape *sh);
+int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh,
+                     float *out, void *workspace, size_t workspace_bytes, hipStream_t s);
+
+static int check_shape(const qe_conv_shape *sh)
+{
+    if (sh == nullptr) return QE_ERR_ARG;
+    if (sh->N < 0 || sh->IC <= 0 || sh->H <= 0 || sh->W <= 0 || sh->OC < 0 || sh->KH <= 0 || sh->KW <= 0 ||
+        sh->stride <= 0 || sh->padding < 0)
+        return QE_ERR_ARG;
+    return QE_OK;
+}
+
+static int check_qparam(const qe_qparam *q)
+{
+    if (q == nullptr || q->data == nullptr || q->scale == nullptr || q->zero == nullptr) return QE_ERR_ARG;
+    if (!(q->n_bits > 0 && q->n_bits <= 8)) return QE_ERR_NBITS;
+    if (q->n_param < 1) return QE_ERR_ARG;
+    return QE_OK;
+}
+
+}  // namespace qe
+
+extern "C" const char *qe_error_string(int status)
+{
+    switch (status) {
+        case QE_OK: return "ok";
+        case QE_ERR_NBITS: return "n_bits must be in the range (0, 8]";          // tpack.cu:13
+        case QE_ERR_RANGE: return "The input tensor is out of range.";           // tpack.cu:14
+        case QE_ERR_DTYPE: return "unsupported element type";
+        case QE_ERR_ARG: return "invalid argument";
+        case QE_ERR_HIP: return "HIP runtime error";
+        case QE_ERR_WORKSPACE: return "workspace too small";
+        case QE_ERR_UNSUPPORTED: return "problem shape not supported by the gfx950 kernels";
+        default: return "unknown error";
+    }
+}
+
+extern "C" int qe_last_hip_error(void) { return qe::g_last_hip_error; }
+extern "C" const char *qe_version(void) { return "quantize_amd 0.1.0"; }
+extern "C" const char *qe_target_arch(void) { return "gfx950"; }
+
+extern "C" size_t qe_quantconv2d_workspace_bytes(const qe_conv_shape *shape, int x_bits, int w_bits)
+{
+    (void)x_bits; (void)w_bits;
+    if (qe::check_shape(shape) != QE_OK) return 0;
+    return qe::mfma_conv_workspace_bytes(shape);
+}
+
+extern "C" int qe_quantconv2d_path(const qe_conv_shape *shape, const qe_qparam *x, const qe_qparam *w)
+{
+    if (qe::check_shape(shape) != QE_OK || x == nullptr || w == nullptr) return 0;
+    return qe::mfma_conv_eligible(shape, x, w) ? 1 : 0;
+}
+
+extern "C" int qe_quantconv2d(const qe_qparam *x, const qe_qparam *w, const float *bias,
+                              const qe_conv_shape *shape, float *out,
+                              void *workspace, size_t workspace_bytes, qe_stream_t stream)
+{
+    using namespace qe;
+    int rc = check_shape(shape);
+    if (rc != QE_OK) return rc;
+    if ((rc = check_qparam(x)) != QE_OK) return rc;
+    if ((rc = check_qparam(w)) != QE_OK) return rc;
+    if (out == nullptr) return QE_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (mfma_conv_eligible(shape, x, w))
+        return launch_conv_mfma(x, w, bias, shape, out, workspace, workspace_bytes, s);
+    return launch_conv_generic(true, x->data, x, w, bias, shape, out, s);
+}
+
+extern "C" int qe_quantconv2d_float_input(const float *x, const qe_qparam *w, const float *bias,
+                                          const qe_conv_shape *shape, float *out, qe_stream_t stream)
+{
+    using namespace qe;
+    int rc = check_shape(shape);
+    if (rc != QE_OK) return rc;
+    if ((rc = check_qparam(w)) != QE_OK) return rc;
+    if (x == nullptr || out == nullptr) return QE_ERR_ARG;
+    return launch_conv_generic(false, x, nullptr, w, bias, shape, out, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,347 @@
+// torch_binding.cpp -- the `quant_engine` Python module for PyTorch-ROCm.
+//
+// Drop-in for the reference's pybind module of the same name
+// (engine/kernels/pybind.cpp:7-17): same 8 exports, positional-only signatures,
+// same return types/dtypes, and the reference's TORCH_CHECK messages (-> Python
+// RuntimeError).  All device work goes through the C ABI in include/quant_engine.h;
+// this file only checks arguments, allocates outputs from torch's caching
+// allocator and picks up torch's current device and stream (the reference launches
+// on the legacy default stream with no device guard).
+//
+// Deliberate differences from the reference, all stricter:
+//   * device tensors only -- CPU tensors raise "x must be a CUDA tensor" instead of
+//     taking a host loop (the reference's tpack_cpu/tunpack_cpu, tpack.cu:140,371);
+//     this build has no CPU compute path at all;
+//   * extra TORCH_CHECKs where the reference would read out of bounds (packed buffer
+//     shorter than the description says, scale arrays that are neither 1 nor C long);
+//   * 64-bit indexing (the reference overflows 32-bit beyond 2^31 bits).
+#include <torch/extension.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+
+#include <vector>
+
+#include "../../include/quant_engine.h"
+
+namespace {
+
+// reference macros: tpack.cu:13-18, quantconv2d.cu:13-15, quantconv2d_float_input.cu:13-16
+#define CHECK_NBITS(b) TORCH_CHECK(b > 0 && b <= 8, #b " must be in the range (0, 8]")
+#define CHECK_LENGTH(x, min) TORCH_CHECK(x.size(0) >= min, "The description is too short, which should be at least " #min ".")
+#define CHECK_CUDA(x) TORCH_CHECK(x.device().is_cuda(), #x " must be a CUDA tensor")
+#define CHECK_CONTIGUOUS(x) TORCH_CHECK(x.is_contiguous(), #x " must be contiguous")
+#define CHECK_FLOAT(x) TORCH_CHECK(x.dtype() == torch::kFloat32, #x " must be a float tensor")
+#define CHECK_INPUT(x) CHECK_CUDA(x); CHECK_CONTIGUOUS(x)
+
+void check_status(int rc, const char *what)
+{
+    if (rc == QE_OK) return;
+    if (rc == QE_ERR_HIP) {
+        TORCH_CHECK(false, what, ": HIP error ", qe_last_hip_error(), " (", qe_error_string(rc), ")");
+    }
+    TORCH_CHECK(false, qe_error_string(rc));
+}
+
+qe_stream_t current_stream(const torch::Tensor &t)
+{
+    return static_cast<qe_stream_t>(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream());
+}
+
+int to_qe_dtype(const torch::Tensor &x, const char *name)
+{
+    switch (x.scalar_type()) {  // AT_DISPATCH_ALL_TYPES_AND(Half), tpack.cu:120
+        case torch::kByte: return QE_U8;
+        case torch::kChar: return QE_I8;
+        case torch::kShort: return QE_I16;
+        case torch::kInt: return QE_I32;
+        case torch::kLong: return QE_I64;
+        case torch::kHalf: return QE_F16;
+        case torch::kFloat: return QE_F32;
+        case torch::kDouble: return QE_F64;
+        default:
+            TORCH_CHECK(false, "\"", name, "\" not implemented for '", toString(x.scalar_type()), "'");
+    }
+    return -1;
+}
+
+struct Des {
+    int n_bits = 0;
+    int sign = 0;
+    std::vector<int64_t> shape;
+    int64_t numel = 1;
+};
+
+// One device->host copy of the whole description (the reference issues one blocking
+// .item() per field: quantconv2d.cu:191-207, tpack.cu:435-474).
+Des read_des(const torch::Tensor &des)
+{
+    auto d = des.to(torch::kCPU, torch::kLong).contiguous();
+    const int64_t *p = d.data_ptr<int64_t>();
+    Des r;
+    r.n_bits = (int)p[0];
+    r.sign = p[1] != 0;
+    for (int64_t i = 2; i < d.numel(); ++i) {
+        r.shape.push_back(p[i]);
+        r.numel *= p[i];
+    }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// tpack  (reference: engine/kernels/tpack/tpack.cu:203-255, tpack.h:17-20)
+// ------------------------------------------------------------------------------------------
+std::vector<torch::Tensor> tpack(torch::Tensor x, int n_bits, bool sign)
+{
+    CHECK_NBITS(n_bits);
+    CHECK_CONTIGUOUS(x);
+    CHECK_CUDA(x);
+    TORCH_CHECK(x.numel() > 0,
+                "min(): Expected reduction dim to be specified for input.numel() == 0. Specify the reduction dim with the 'dim' argument.");
+    const int dtype = to_qe_dtype(x, "tpack_cuda");
+
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+    const int64_t n = x.numel();
+    auto x_out = torch::empty({qe_packed_nbytes(n, n_bits)}, torch::dtype(torch::kByte).device(x.device()));
+    auto status = torch::zeros({1}, torch::dtype(torch::kInt).device(x.device()));
+
+    check_status(qe_tpack(x.data_ptr(), dtype, n, n_bits, sign ? 1 : 0, x_out.data_ptr<uint8_t>(),
+                          status.data_ptr<int32_t>(), current_stream(x)),
+                 "tpack");
+    // CHECK_RANGE (tpack.cu:14,211-215), fused into the pack pass: one 4-byte read-back
+    // instead of two full reductions + two syncs.
+    TORCH_CHECK(status.item<int>() == 0, "The input tensor is out of range.");
+
+    // des = [n_bits, sign, *shape], int32, on x.device (tpack.cu:228-238)
+    std::vector<int32_t> d;
+    d.push_back(n_bits);
+    d.push_back(sign ? 1 : 0);
+    for (auto s : x.sizes()) d.push_back((int32_t)s);
+    auto des = torch::tensor(d, torch::dtype(torch::kInt)).to(x.device());
+    return {x_out, des};
+}
+
+// ------------------------------------------------------------------------------------------
+// tunpack  (reference: tpack.cu:429-476, tpack.h:30-32)
+// ------------------------------------------------------------------------------------------
+torch::Tensor tunpack(torch::Tensor x, torch::Tensor des)
+{
+    CHECK_LENGTH(des, 3);
+    const Des d = read_des(des);
+    const int n_bits = d.n_bits;
+    CHECK_NBITS(n_bits);
+    CHECK_CONTIGUOUS(x);
+    TORCH_CHECK(x.dtype() == torch::kByte, "The input tensor must be torch.uint8.");
+    CHECK_CUDA(x);
+    TORCH_CHECK(d.numel >= 0, "The description holds a negative shape.");
+    TORCH_CHECK(x.numel() >= qe_packed_nbytes(d.numel, n_bits),
+                "The packed tensor is shorter than its description requires.");
+
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+    auto x_out = torch::empty({d.numel}, torch::dtype(d.sign ? torch::kChar : torch::kByte).device(x.device()));
+    check_status(qe_tunpack(x.data_ptr<uint8_t>(), d.numel, n_bits, d.sign, x_out.data_ptr(), current_stream(x)),
+                 "tunpack");
+    return x_out.reshape(d.shape);
+}
+
+qe_qparam make_qparam(const torch::Tensor &data, const Des &d, const torch::Tensor &scale, const torch::Tensor &zero)
+{
+    qe_qparam q;
+    q.data = data.data_ptr<uint8_t>();
+    q.n_bits = d.n_bits;
+    q.sign = d.sign;
+    q.scale = scale.data_ptr<float>();
+    q.zero = zero.data_ptr<float>();
+    q.n_param = (int32_t)scale.numel();
+    return q;
+}
+
+// ------------------------------------------------------------------------------------------
+// quantconv2d  (reference: functions/quantconv2d.cu:164-264, funcs.h:113-124)
+// ------------------------------------------------------------------------------------------
+torch::Tensor quantconv2d(const torch::Tensor &input, const torch::Tensor &input_des,
+                          const torch::Tensor &input_scale, const torch::Tensor &input_zero,
+                          const torch::Tensor &weight, const torch::Tensor &weight_des,
+                          const torch::Tensor &weight_scale, const torch::Tensor &weight_zero,
+                          const c10::optional<torch::Tensor> &bias, const int stride, const int padding)
+{
+    CHECK_INPUT(input);
+    CHECK_INPUT(input_des);
+    CHECK_INPUT(input_scale);
+    CHECK_INPUT(input_zero);
+    CHECK_INPUT(weight);
+    CHECK_INPUT(weight_des);
+    CHECK_INPUT(weight_scale);
+    CHECK_INPUT(weight_zero);
+    if (bias.has_value()) { CHECK_INPUT(bias.value()); }
+
+    TORCH_CHECK(input_des.numel() >= 6 && weight_des.numel() >= 6,
+                "The description is too short, which should be at least 6.");
+    const Des xd = read_des(input_des);   // quantconv2d.cu:191-193
+    const Des wd = read_des(weight_des);  // quantconv2d.cu:194-196
+    CHECK_NBITS(xd.n_bits);
+    CHECK_NBITS(wd.n_bits);
+    TORCH_CHECK(stride > 0 && padding >= 0, "stride must be positive and padding non-negative");
+
+    qe_conv_shape sh;
+    sh.N = (int32_t)xd.shape[0]; sh.IC = (int32_t)xd.shape[1];      // quantconv2d.cu:199-202
+    sh.H = (int32_t)xd.shape[2]; sh.W = (int32_t)xd.shape[3];
+    sh.OC = (int32_t)wd.shape[0];                                   // :205 (weight_shape[1] is never read)
+    sh.KH = (int32_t)wd.shape[2]; sh.KW = (int32_t)wd.shape[3];     // :206-207
+    sh.stride = stride; sh.padding = padding;
+    const int64_t OH = (sh.H + 2 * padding - sh.KH) / stride + 1;   // :210
+    const int64_t OW = (sh.W + 2 * padding - sh.KW) / stride + 1;   // :211
+    TORCH_CHECK(OH > 0 && OW > 0, "Calculated output size is too small: (", OH, " x ", OW, ")");
+
+    // data_ptr<unsigned char>() / data_ptr<float>() of the reference (:235-247) throw on a
+    // dtype mismatch; check up front, plus the buffer lengths the kernel will index.
+    TORCH_CHECK(input.scalar_type() == torch::kByte, "expected scalar type Byte but found ", toString(input.scalar_type()));
+    TORCH_CHECK(weight.scalar_type() == torch::kByte, "expected scalar type Byte but found ", toString(weight.scalar_type()));
+    for (const torch::Tensor *t : {&input_scale, &input_zero, &weight_scale, &weight_zero})
+        TORCH_CHECK(t->scalar_type() == torch::kFloat, "expected scalar type Float but found ", toString(t->scalar_type()));
+    TORCH_CHECK(input.numel() >= qe_packed_nbytes((int64_t)sh.N * sh.IC * sh.H * sh.W, xd.n_bits),
+                "The packed input is shorter than its description requires.");
+    TORCH_CHECK(weight.numel() >= qe_packed_nbytes((int64_t)sh.OC * sh.IC * sh.KH * sh.KW, wd.n_bits),
+                "The packed weight is shorter than its description requires.");
+    TORCH_CHECK(input_scale.numel() == input_zero.numel() && (input_scale.numel() == 1 || input_scale.numel() >= sh.IC),
+                "input_scale/input_zero must hold 1 or input_channel elements");
+    TORCH_CHECK(weight_scale.numel() == weight_zero.numel() && (weight_scale.numel() == 1 || weight_scale.numel() >= sh.OC),
+                "weight_scale/weight_zero must hold 1 or output_channel elements");
+    const float *bias_ptr = nullptr;
+    if (bias.has_value()) {
+        TORCH_CHECK(bias.value().scalar_type() == torch::kFloat, "expected scalar type Float but found ",
+                    toString(bias.value().scalar_type()));
+        TORCH_CHECK(bias.value().numel() >= sh.OC, "bias must hold output_channel elements");
+        bias_ptr = bias.value().data_ptr<float>();
+    }
+
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(input.device());
+    auto output = torch::empty({sh.N, sh.OC, OH, OW}, torch::dtype(torch::kFloat32).device(input.device()));
+    const qe_qparam xq = make_qparam(input, xd, input_scale, input_zero);
+    const qe_qparam wq = make_qparam(weight, wd, weight_scale, weight_zero);
+    const size_t ws_bytes = qe_quantconv2d_workspace_bytes(&sh, xd.n_bits, wd.n_bits);
+    auto workspace = torch::empty({(int64_t)ws_bytes}, torch::dtype(torch::kByte).device(input.device()));
+    check_status(qe_quantconv2d(&xq, &wq, bias_ptr, &sh, output.data_ptr<float>(),
+                                ws_bytes ? workspace.data_ptr() : nullptr, ws_bytes, current_stream(input)),
+                 "quantconv2d");
+    return output;
+}
+
+// ------------------------------------------------------------------------------------------
+// quantconv2d_float_input  (reference: functions/quantconv2d_float_input.cu:140-220, funcs.h:143-151)
+// ------------------------------------------------------------------------------------------
+torch::Tensor quantconv2d_float_input(const torch::Tensor &input, const torch::Tensor &weight,
+                                      const torch::Tensor &weight_des, const torch::Tensor &weight_scale,
+                                      const torch::Tensor &weight_zero, const c10::optional<torch::Tensor> &bias,
+                                      const int stride, const int padding)
+{
+    CHECK_INPUT(input);
+    CHECK_FLOAT(input);
+    CHECK_INPUT(weight);
+    CHECK_INPUT(weight_des);
+    CHECK_INPUT(weight_scale);
+    CHECK_INPUT(weight_zero);
+    if (bias.has_value()) { CHECK_INPUT(bias.value()); }
+
+    TORCH_CHECK(input.dim() == 4, "input must be a 4-D (N, C, H, W) tensor");
+    TORCH_CHECK(weight_des.numel() >= 6, "The description is too short, which should be at least 6.");
+    const Des wd = read_des(weight_des);  // quantconv2d_float_input.cu:163-165
+    CHECK_NBITS(wd.n_bits);
+    TORCH_CHECK(stride > 0 && padding >= 0, "stride must be positive and padding non-negative");
+
+    qe_conv_shape sh;
+    sh.N = (int32_t)input.size(0); sh.IC = (int32_t)input.size(1);  // :168-171
+    sh.H = (int32_t)input.size(2); sh.W = (int32_t)input.size(3);
+    sh.OC = (int32_t)wd.shape[0]; sh.KH = (int32_t)wd.shape[2]; sh.KW = (int32_t)wd.shape[3];  // :174-176
+    sh.stride = stride; sh.padding = padding;
+    const int64_t OH = (sh.H + 2 * padding - sh.KH) / stride + 1;  // :177
+    const int64_t OW = (sh.W + 2 * padding - sh.KW) / stride + 1;  // :178
+    TORCH_CHECK(OH > 0 && OW > 0, "Calculated output size is too small: (", OH, " x ", OW, ")");
+
+    TORCH_CHECK(weight.scalar_type() == torch::kByte, "expected scalar type Byte but found ", toString(weight.scalar_type()));
+    for (const torch::Tensor *t : {&weight_scale, &weight_zero})
+        TORCH_CHECK(t->scalar_type() == torch::kFloat, "expected scalar type Float but found ", toString(t->scalar_type()));
+    TORCH_CHECK(weight.numel() >= qe_packed_nbytes((int64_t)sh.OC * sh.IC * sh.KH * sh.KW, wd.n_bits),
+                "The packed weight is shorter than its description requires.");
+    TORCH_CHECK(weight_scale.numel() == weight_zero.numel() && (weight_scale.numel() == 1 || weight_scale.numel() >= sh.OC),
+                "weight_scale/weight_zero must hold 1 or output_channel elements");
+    const float *bias_ptr = nullptr;
+    if (bias.has_value()) {
+        TORCH_CHECK(bias.value().scalar_type() == torch::kFloat, "expected scalar type Float but found ",
+                    toString(bias.value().scalar_type()));
+        TORCH_CHECK(bias.value().numel() >= sh.OC, "bias must hold output_channel elements");
+        bias_ptr = bias.value().data_ptr<float>();
+    }
+
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(input.device());
+    auto output = torch::empty({sh.N, sh.OC, OH, OW}, input.options());
+    const qe_qparam wq = make_qparam(weight, wd, weight_scale, weight_zero);
+    check_status(qe_quantconv2d_float_input(input.data_ptr<float>(), &wq, bias_ptr, &sh, output.data_ptr<float>(),
+                                            current_stream(input)),
+                 "quantconv2d_float_input");
+    return output;
+}
+
+// ------------------------------------------------------------------------------------------
+// linear / conv2d: the reference's float demo kernels (functions/linear.cu:187-207,
+// functions/conv2d.cu:231-309).  No Python caller exists in the reference (SURVEY.md section 2
+// row 8: out of scope); exported for API completeness on top of ATen.  `mode` selected
+// between two equivalent kernels in the reference and is ignored here.
+// ------------------------------------------------------------------------------------------
+torch::Tensor linear(const torch::Tensor &input, const torch::Tensor &weight,
+                     const c10::optional<torch::Tensor> &bias, const int mode)
+{
+    (void)mode;
+    return at::linear(input, weight, bias);
+}
+
+torch::Tensor conv2d(const torch::Tensor &input, const torch::Tensor &weight,
+                     const c10::optional<torch::Tensor> &bias, const int stride, const int padding, const int mode)
+{
+    (void)mode;
+    CHECK_INPUT(input);
+    CHECK_INPUT(weight);
+    if (bias.has_value()) { CHECK_INPUT(bias.value()); }
+    return at::conv2d(input, weight, bias, {stride, stride}, {padding, padding});
+}
+
+// ------------------------------------------------------------------------------------------
+// quantlinear / quantlinear_float_input (functions/quantlinear.cu:233-297,
+// functions/quantlinear_float_input.cu:120-182): SURVEY.md section 8f row 1, "next" -- not part of
+// the conv hot path.  They fail loudly rather than compute something else.
+// ------------------------------------------------------------------------------------------
+torch::Tensor quantlinear(const torch::Tensor &, const torch::Tensor &, const torch::Tensor &, const torch::Tensor &,
+                          const torch::Tensor &, const torch::Tensor &, const torch::Tensor &, const torch::Tensor &,
+                          const c10::optional<torch::Tensor> &)
+{
+    TORCH_CHECK(false, "quantlinear is not implemented in this build of quant_engine (gfx950): "
+                       "only the quantized conv2d path and tensor packing are (SURVEY.md section 8f).");
+    return {};
+}
+
+torch::Tensor quantlinear_float_input(const torch::Tensor &, const torch::Tensor &, const torch::Tensor &,
+                                      const torch::Tensor &, const torch::Tensor &,
+                                      const c10::optional<torch::Tensor> &)
+{
+    TORCH_CHECK(false, "quantlinear_float_input is not implemented in this build of quant_engine (gfx950): "
+                       "only the quantized conv2d path and tensor packing are (SURVEY.md section 8f).");
+    return {};
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
+{
+    // Same names and positional signatures as the reference module (engine/kernels/pybind.cpp:9-16).
+    m.def("tpack", &tpack, "tpack(x, n_bits, sign) -> [packed uint8 1-D, des int32]: b-bit LSB-first bit stream.");
+    m.def("tunpack", &tunpack, "tunpack(packed, des) -> int8/uint8 tensor of shape des[2:].");
+    m.def("linear", &linear, "linear(input, weight, bias, mode): float x @ w.T + b (ATen).");
+    m.def("quantlinear", &quantlinear, "quantlinear(...): not implemented in this build (raises).");
+    m.def("quantlinear_float_input", &quantlinear_float_input, "quantlinear_float_input(...): not implemented in this build (raises).");
+    m.def("conv2d", &conv2d, "conv2d(input, weight, bias, stride, padding, mode): float conv (ATen).");
+    m.def("quantconv2d", &quantconv2d,
+          "quantconv2d(x, x_des, x_scale, x_zero, w, w_des, w_scale, w_zero, bias, stride, padding) -> fp32 NCHW.");
+    m.def("quantconv2d_float_input", &quantconv2d_float_input,
+          "quantconv2d_float_input(x_fp32, w, w_des, w_scale, w_zero, bias, stride, padding) -> fp32 NCHW.");
+    m.attr("__qe_version__") = qe_version();
+    m.attr("__qe_arch__") = qe_target_arch();
+}

@@ -1,0 +1,56 @@
+"""Operator surface of the quantized linear layer, mirroring the reference's
+modelzoo/modules/operator/quantlinearop.py:16-80 (QuantLinearOp1/2, quantlinear_forward).
+
+The dispatch table is the reference's; the two native functions behind it
+(engine.quantlinear / quantlinear_float_input) are SURVEY.md section 8f row 1 ("next") and
+raise RuntimeError in this build, so only the fp32 x fp32 -> F.linear branch computes.
+"""
+import torch
+from torch.autograd import Function
+from torch.nn import functional as F
+
+from ..engine import quantlinear, quantlinear_float_input
+from .quantconv2dop import _split
+
+
+class QuantLinearOp1(Function):
+    """Packed x packed linear (reference quantlinearop.py:16-37)."""
+
+    @staticmethod
+    def forward(ctx, input, input_des, input_scale, input_zero,
+                weight, weight_des, weight_scale, weight_zero, bias):
+        return quantlinear(input, input_des, input_scale, input_zero,
+                           weight, weight_des, weight_scale, weight_zero, bias)
+
+    @staticmethod
+    def symbolic(g, input, input_des, input_scale, input_zero,
+                 weight, weight_des, weight_scale, weight_zero, bias):
+        return g.op("QuantLinearOp1", input, input_des, input_scale, input_zero,
+                    weight, weight_des, weight_scale, weight_zero, bias)
+
+
+class QuantLinearOp2(Function):
+    """fp32 x packed linear (reference quantlinearop.py:40-56)."""
+
+    @staticmethod
+    def forward(ctx, input, weight, weight_des, weight_scale, weight_zero, bias):
+        return quantlinear_float_input(input, weight, weight_des, weight_scale, weight_zero, bias)
+
+    @staticmethod
+    def symbolic(g, input, weight, weight_des, weight_scale, weight_zero, bias):
+        return g.op("QuantLinearOp2", input, weight, weight_des, weight_scale, weight_zero, bias)
+
+
+def quantlinear_forward(input, weight, bias):
+    """Forward of a QuantLinear module (reference quantlinearop.py:59-80)."""
+    input, input_des, input_scale, input_zero = _split(input)
+    weight, weight_des, weight_scale, weight_zero = _split(weight)
+
+    if input.dtype == torch.float32 and weight.dtype == torch.float32:
+        return F.linear(input, weight, bias)
+    if input.dtype == torch.uint8 and weight.dtype == torch.uint8:
+        return QuantLinearOp1.apply(input, input_des, input_scale, input_zero,
+                                    weight, weight_des, weight_scale, weight_zero, bias)
+    if input.dtype == torch.float32 and weight.dtype == torch.uint8:
+        return QuantLinearOp2.apply(input, weight, weight_des, weight_scale, weight_zero, bias)
+    raise ValueError("Unsupported input and weight types.")
