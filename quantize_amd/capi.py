@@ -1,0 +1,164 @@
+"""ctypes view of the C ABI (include/quant_engine.h) -- what a non-torch host would bind.
+
+Tensors are only used here as device-memory handles (data_ptr) and for the current HIP
+stream; every compute call goes straight into libqe_hip.so.  Used by bench.py and by the
+`-m gpu` parity tests, which must exercise the C ABI itself and not only the torch module.
+"""
+import ctypes
+import os
+
+from . import loader
+
+_lib = None
+
+QE_OK = 0
+DTYPES = {"uint8": 0, "int8": 1, "int16": 2, "int32": 3, "int64": 4,
+          "float16": 5, "float32": 6, "float64": 7}
+
+# every symbol include/quant_engine.h declares
+SYMBOLS = ["qe_error_string", "qe_last_hip_error", "qe_version", "qe_target_arch", "qe_packed_nbytes",
+           "qe_tpack", "qe_tunpack", "qe_quantconv2d_workspace_bytes", "qe_quantconv2d",
+           "qe_quantconv2d_float_input", "qe_quantconv2d_path"]
+
+
+class QeConvShape(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("N", "IC", "H", "W", "OC", "KH", "KW", "stride", "padding")]
+
+
+class QeQParam(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("n_bits", ctypes.c_int32), ("sign", ctypes.c_int32),
+                ("scale", ctypes.c_void_p), ("zero", ctypes.c_void_p), ("n_param", ctypes.c_int32)]
+
+
+class QeError(RuntimeError):
+    pass
+
+
+def lib():
+    """dlopen libqe_hip.so (no GPU needed to load it) and declare the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = loader.lib_path()
+    if not os.path.exists(path):
+        raise ImportError("libqe_hip.so not built: run `python -m quantize_amd.build`. No fallback exists.")
+    L = ctypes.CDLL(path)
+    vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+    L.qe_error_string.restype = ctypes.c_char_p
+    L.qe_error_string.argtypes = [i32]
+    L.qe_last_hip_error.restype = i32
+    L.qe_version.restype = ctypes.c_char_p
+    L.qe_target_arch.restype = ctypes.c_char_p
+    L.qe_packed_nbytes.restype = i64
+    L.qe_packed_nbytes.argtypes = [i64, i32]
+    L.qe_tpack.restype = i32
+    L.qe_tpack.argtypes = [vp, i32, i64, i32, i32, vp, vp, vp]
+    L.qe_tunpack.restype = i32
+    L.qe_tunpack.argtypes = [vp, i64, i32, i32, vp, vp]
+    L.qe_quantconv2d_workspace_bytes.restype = sz
+    L.qe_quantconv2d_workspace_bytes.argtypes = [ctypes.POINTER(QeConvShape), i32, i32]
+    L.qe_quantconv2d.restype = i32
+    L.qe_quantconv2d.argtypes = [ctypes.POINTER(QeQParam), ctypes.POINTER(QeQParam), vp,
+                                 ctypes.POINTER(QeConvShape), vp, vp, sz, vp]
+    L.qe_quantconv2d_float_input.restype = i32
+    L.qe_quantconv2d_float_input.argtypes = [vp, ctypes.POINTER(QeQParam), vp, ctypes.POINTER(QeConvShape), vp, vp]
+    L.qe_quantconv2d_path.restype = i32
+    L.qe_quantconv2d_path.argtypes = [ctypes.POINTER(QeConvShape), ctypes.POINTER(QeQParam), ctypes.POINTER(QeQParam)]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != QE_OK:
+        L = lib()
+        msg = L.qe_error_string(rc).decode()
+        if rc == 5:
+            msg += " (hipError_t %d)" % L.qe_last_hip_error()
+        raise QeError(msg)
+
+
+def _stream(stream=None):
+    import torch
+    s = torch.cuda.current_stream() if stream is None else stream
+    return ctypes.c_void_p(s.cuda_stream)
+
+
+def packed_nbytes(n, n_bits):
+    return int(lib().qe_packed_nbytes(int(n), int(n_bits)))
+
+
+def tpack(x, n_bits, sign, out=None, status=None, stream=None):
+    """qe_tpack on a contiguous device tensor. Returns (packed uint8 tensor, status int32[1] tensor)."""
+    import torch
+    assert x.is_cuda and x.is_contiguous()
+    n = x.numel()
+    if out is None:
+        out = torch.empty(packed_nbytes(n, n_bits), dtype=torch.uint8, device=x.device)
+    if status is None:
+        status = torch.zeros(1, dtype=torch.int32, device=x.device)
+    check(lib().qe_tpack(x.data_ptr(), DTYPES[str(x.dtype).replace("torch.", "")], n, int(n_bits),
+                         1 if sign else 0, out.data_ptr(), status.data_ptr(), _stream(stream)))
+    return out, status
+
+
+def tunpack(packed, n, n_bits, sign, out=None, stream=None):
+    import torch
+    assert packed.is_cuda and packed.is_contiguous() and packed.dtype == torch.uint8
+    if out is None:
+        out = torch.empty(n, dtype=torch.int8 if sign else torch.uint8, device=packed.device)
+    check(lib().qe_tunpack(packed.data_ptr(), int(n), int(n_bits), 1 if sign else 0, out.data_ptr(),
+                           _stream(stream)))
+    return out
+
+
+def conv_shape(N, IC, H, W, OC, KH, KW, stride, padding):
+    return QeConvShape(int(N), int(IC), int(H), int(W), int(OC), int(KH), int(KW), int(stride), int(padding))
+
+
+def out_hw(sh):
+    return ((sh.H + 2 * sh.padding - sh.KH) // sh.stride + 1, (sh.W + 2 * sh.padding - sh.KW) // sh.stride + 1)
+
+
+def qparam(data, n_bits, sign, scale, zero):
+    """Packed operand: uint8 stream + fp32 scale/zero tensors (1 element = per tensor)."""
+    assert scale.numel() == zero.numel()
+    q = QeQParam(data.data_ptr(), int(n_bits), 1 if sign else 0, scale.data_ptr(), zero.data_ptr(),
+                 int(scale.numel()))
+    q._keep = (data, scale, zero)  # keep the tensors alive as long as the struct
+    return q
+
+
+def workspace_bytes(sh, x_bits, w_bits):
+    return int(lib().qe_quantconv2d_workspace_bytes(ctypes.byref(sh), int(x_bits), int(w_bits)))
+
+
+def conv_path(sh, xq, wq):
+    return int(lib().qe_quantconv2d_path(ctypes.byref(sh), ctypes.byref(xq), ctypes.byref(wq)))
+
+
+def quantconv2d(xq, wq, bias, sh, out=None, workspace=None, stream=None):
+    import torch
+    dev = wq._keep[0].device
+    OH, OW = out_hw(sh)
+    if out is None:
+        out = torch.empty((sh.N, sh.OC, OH, OW), dtype=torch.float32, device=dev)
+    need = workspace_bytes(sh, xq.n_bits, wq.n_bits)
+    if workspace is None and need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    check(lib().qe_quantconv2d(ctypes.byref(xq), ctypes.byref(wq),
+                               None if bias is None else bias.data_ptr(), ctypes.byref(sh), out.data_ptr(),
+                               None if workspace is None else workspace.data_ptr(),
+                               0 if workspace is None else workspace.numel(), _stream(stream)))
+    return out
+
+
+def quantconv2d_float_input(x, wq, bias, sh, out=None, stream=None):
+    import torch
+    assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32
+    OH, OW = out_hw(sh)
+    if out is None:
+        out = torch.empty((sh.N, sh.OC, OH, OW), dtype=torch.float32, device=x.device)
+    check(lib().qe_quantconv2d_float_input(x.data_ptr(), ctypes.byref(wq),
+                                           None if bias is None else bias.data_ptr(), ctypes.byref(sh),
+                                           out.data_ptr(), _stream(stream)))
+    return out
