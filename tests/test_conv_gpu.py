@@ -178,6 +178,7 @@ def test_headline_distribution_1e5(engine):
     rng = np.random.RandomState(3)
     layers = resnet50.conv_layers()
     seen = set()
+    paths = {}
     for layer in layers:
         sig = (layer.IC, layer.OC, layer.K, layer.stride, layer.pad, layer.H)
         if sig in seen:
@@ -188,6 +189,9 @@ def test_headline_distribution_1e5(engine):
                             8, 1, 8, 1, w_pc=True, a_pc=False, zeros=False, bias=True)
         y, o32, o64 = _run_case(engine, case, via_capi=True)
         assert np.abs(y.astype(np.float64) - o64).max() <= 1e-5, layer.name
+        paths[layer.name] = case["path"]
+    # every ResNet-50 conv runs on the int8 MFMA kernel
+    assert all(v == 1 for v in paths.values()), paths
     assert len(seen) == 23
 
 
