@@ -19,8 +19,9 @@ CSRC = os.path.join(_HERE, "csrc")
 EXT_DIR = os.path.join(_HERE, "_ext")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
-HIP_SOURCES = ["qe_api.hip", "qe_tpack.hip", "qe_conv_generic.hip", "qe_conv_mfma.hip"]
-HIP_HEADERS = ["qe_common.h", os.path.join(INCLUDE, "quant_engine.h")]
+HIP_SOURCES = ["qe_api.hip", "qe_tpack.hip", "qe_conv_generic.hip", "qe_conv_mfma.hip",
+               "qe_conv_mfma_i0.hip", "qe_conv_mfma_i1.hip", "qe_conv_mfma_i2.hip"]
+HIP_HEADERS = ["qe_common.h", "qe_conv_mfma_kernel.hpp", os.path.join(INCLUDE, "quant_engine.h")]
 ARCH = "gfx950"
 
 
@@ -41,18 +42,36 @@ def module_path():
 
 
 def build_hip(force=False, verbose=False):
+    """Each .hip translation unit -> object (in parallel: the MFMA instantiation units dominate),
+    then one link into libqe_hip.so."""
+    from concurrent.futures import ThreadPoolExecutor
+
     os.makedirs(EXT_DIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
-    out = lib_path()
-    if not force and not _newer(out, deps):
-        return out
+    obj_dir = os.path.join(EXT_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-I", INCLUDE, "-o", out] + srcs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    common = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+              "-I", INCLUDE]
+    jobs, objs = [], []
+    for src in HIP_SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(obj_dir, src.replace(".hip", ".o"))
+        objs.append(op)
+        if force or _newer(op, [sp] + hdrs):
+            jobs.append(common + ["-c", sp, "-o", op])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) - 1))) as ex:
+            list(ex.map(run, jobs))
+    out = lib_path()
+    if jobs or not os.path.exists(out):
+        run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs)
     return out
 
 

@@ -1,0 +1,402 @@
+// qe_conv_mfma_kernel.hpp -- the int8 MFMA implicit-GEMM convolution kernel template (gfx950).
+// Design notes: qe_conv_mfma.hip.  Everything in the hot loop is straight-line code: loads are
+// unconditional (clamped address + mask) because hipcc waits vmcnt(0) after every load it has to
+// branch around, which serialises the whole activation fetch into one HBM round trip per dword.
+#pragma once
+#include "qe_common.h"
+
+#include <type_traits>
+
+namespace qe {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int MF_THREADS = 256;
+constexpr int MF_UNITS = 2;        // staging units (16 ch x 4 px) per thread per chunk
+constexpr int MF_TRASH = 64;       // per-lane LDS slots that swallow masked-off staging writes
+constexpr int MF_MAX_LDS = 64 * 1024;
+
+struct MfmaArgs {
+    const uint8_t *x;
+    int64_t x_bytes;           // length of the packed activation stream (>= 8)
+    const float *x_zero;       // per tensor
+    int x_bits, x_sign;
+    const int8_t *wt;          // [KK][NG][OCP][16]
+    const float *ep;           // [3][OCP]: alpha = sx*sw, zw', bias
+    const int *ws;             // [OCP][KK+1]: sum_ic a_w per tap, [KK] = all taps
+    float *out;
+    int N, IC, H, W, OC, KH, KW, stride, pad, OH, OW;
+    int OCP, NG, NCH;          // padded oc, 16-channel groups (even), 32-channel chunks
+    int TH, tiles_h, n_pix_tiles, n_oc_tiles;
+    int IHT, IWP, ROWMUL, COLMUL, ni;
+};
+
+// stored code u -> MFMA operand a = q - d = u - c, c = off (signed) | 128 (unsigned 8-bit) | 0
+__host__ __device__ __forceinline__ int code_bias(int n_bits, int sign)
+{
+    return sign ? (1 << (n_bits - 1)) : (n_bits == 8 ? 128 : 0);
+}
+// d: what was subtracted from q on top of the sign offset (added back through the zero point)
+__host__ __device__ __forceinline__ float zero_shift(int n_bits, int sign)
+{
+    return (!sign && n_bits == 8) ? 128.0f : 0.0f;
+}
+
+// 4 consecutive elements of one channel row -> 4 int8 operands in a dword.  `xi` is the image's
+// base (wave-uniform), `off` the element offset inside the image (32-bit), `lim` the last offset at
+// which a full-width read still ends inside the stream.  Branch-free: the read is clamped and the
+// value shifted back; whatever is shifted in belongs to elements that are never valid pixels.
+template <bool X8>
+__device__ __forceinline__ uint32_t fetch_quad(const uint8_t *__restrict__ xi, int off, int64_t lim,
+                                               int n_bits, int cb)
+{
+    if constexpr (X8) {
+        const int offc = off < (int)lim ? off : (int)lim;
+        uint32_t v;
+        __builtin_memcpy(&v, xi + (uint32_t)offc, 4);  // one (possibly unaligned) global_load_dword
+        v >>= 8 * (off - offc);
+        return v ^ 0x80808080u;                        // u - 128 per byte: signed q, or unsigned q - 128
+    } else {
+        const int64_t bit = (int64_t)off * n_bits;
+        const int64_t byte = bit >> 3;
+        const int64_t bc = byte < lim ? byte : lim;
+        uint64_t v;
+        __builtin_memcpy(&v, xi + bc, 8);
+        v >>= ((int)(bit & 7) + 8 * (int)(byte - bc));
+        const uint32_t mask = (1u << n_bits) - 1u;
+        uint32_t r = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t c = (uint32_t)(v >> (j * n_bits)) & mask;
+            r |= ((c - (uint32_t)cb) & 0xffu) << (8 * j);
+        }
+        return r;
+    }
+}
+
+// 4x4 byte transpose: in d0..d3 (one channel each, 4 pixels), out o0..o3 (one pixel each, 4 channels)
+__device__ __forceinline__ void transpose4x4(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3,
+                                             uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3)
+{
+    const uint32_t t0 = __builtin_amdgcn_perm(d1, d0, 0x05010400u);  // d0.b0 d1.b0 d0.b1 d1.b1
+    const uint32_t t1 = __builtin_amdgcn_perm(d1, d0, 0x07030602u);  // d0.b2 d1.b2 d0.b3 d1.b3
+    const uint32_t t2 = __builtin_amdgcn_perm(d3, d2, 0x05010400u);
+    const uint32_t t3 = __builtin_amdgcn_perm(d3, d2, 0x07030602u);
+    o0 = __builtin_amdgcn_perm(t2, t0, 0x05040100u);
+    o1 = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+    o2 = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+    o3 = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+}
+
+// WM x WN waves over (oc strips, pixel column tiles); NIW column tiles per wave; KKT = taps known
+// at compile time (1, 9 = 3x3) or 0 for a runtime tap loop; X8 = 8-bit activations.
+template <int WM, int WN, int NIW, int KKT, bool X8>
+__global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint4 *Xs = reinterpret_cast<uint4 *>(smem);
+
+    constexpr int MT = 32 * WM;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int col = lane & 31, h = lane >> 5;
+
+    // XCD-aware block map: blocks b and b+8 share an XCD (and its L2); the oc-tiles of one pixel
+    // tile get ids that differ by multiples of 8 so they read the same activations from one L2.
+    const int bid = blockIdx.x;
+    const int grp_sz = 8 * a.n_oc_tiles;
+    const int grp = bid / grp_sz, rem = bid - grp * grp_sz;
+    const int pt = grp * 8 + (rem & 7);
+    const int ot = rem >> 3;
+    if (pt >= a.n_pix_tiles) return;
+
+    const int n = pt / a.tiles_h;
+    const int oh0 = (pt - n * a.tiles_h) * a.TH;
+    const int th = min(a.TH, a.OH - oh0);
+    const int NT = th * a.OW;
+    const int ih0 = oh0 * a.stride - a.pad;
+    const int GSZ = a.IHT * a.IWP;
+    const int KK = (KKT > 0) ? KKT : a.KH * a.KW;
+    const int trash = 2 * GSZ + lane;
+    int *sxp = reinterpret_cast<int *>(Xs + 2 * GSZ + MF_TRASH);  // [GSZ] per-input-pixel sums (zw' != 0 only)
+
+    // ---- zero the LDS halo image once: borders / padded channels are never written again ----
+    for (int i = tid; i < 2 * GSZ; i += MF_THREADS) Xs[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < GSZ; i += MF_THREADS) sxp[i] = 0;
+
+    // ---- per-lane pixel bases of the wave's column tiles (uint4 index into Xs) ---------------
+    const int RS = a.stride / a.ROWMUL, CS = a.stride / a.COLMUL;
+    int pixidx[NIW];
+#pragma unroll
+    for (int t = 0; t < NIW; ++t) {
+        const int q = (wn + t * WN) * 32 + col;
+        const int r = q / a.OW, c = q - r * a.OW;
+        pixidx[t] = h * GSZ + ((q < NT) ? (r * RS) * a.IWP + c * CS : 0);
+    }
+
+    // ---- staging: thread <-> (halo row l, column quad iq); its two units are the two 16-channel
+    // groups of the chunk, so the channel of every load is wave-uniform (scalar base + ONE per-thread
+    // 32-bit offset) and nothing needs a per-lane clamp. --------------------------------------
+    const int NQ = (a.W + 3) >> 2;
+    const int HW = a.H * a.W;
+    const int64_t img_off = (int64_t)n * a.IC * HW;                       // elements
+    int u_off;                 // element offset in a channel plane of (row ih, column iw0)
+    int u_sh = 0;              // the row's last quad is read 4 bytes back from the row end and shifted
+    int u_lds[4];              // uint4 index of pixel j in group 0 (+GSZ for group 1), or a trash slot
+    {
+        const int l = tid / NQ, iq = tid - l * NQ;
+        const int ih = ih0 + l * a.ROWMUL;
+        const bool ok = l < a.IHT && ih >= 0 && ih < a.H;
+        int iw0 = 4 * iq;
+        if (iw0 + 4 > a.W) { u_sh = 8 * (iw0 + 4 - a.W); iw0 = a.W - 4; }  // never read past the row (W >= 4)
+        u_off = ok ? ih * a.W + iw0 : 0;
+        if (!ok) u_sh = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int iw = 4 * iq + j;
+            const int cl = iw + a.pad;
+            const int clc = cl / a.COLMUL;
+            const bool pok = ok && iw < a.W && (clc * a.COLMUL == cl) && clc < a.IWP;
+            u_lds[j] = pok ? l * a.IWP + clc : -1;
+        }
+    }
+    const uint8_t *xi = a.x + (X8 ? img_off : 0);   // 8-bit: image base (uniform); sub-8-bit: stream base
+    const int64_t lim8 = a.x_bytes - 8;             // sub-8-bit: last byte offset of a full 8-byte read
+
+    // ---- weight fragment pointer: lane (row col, half h) reads Wt[tap][2c + h][oc][16 B] ------
+    const int8_t *a_base = a.wt + (int64_t)(ot * MT + wm * 32) * 16;  // wave-uniform
+    const uint32_t a_voff = (uint32_t)(h * a.OCP + col) * 16u;           // per lane
+    const int64_t grp_stride = (int64_t)a.OCP * 16;            // one 16-channel group
+    const int64_t tap_stride = (int64_t)a.NG * grp_stride;     // one tap
+    const int cbx = code_bias(a.x_bits, a.x_sign);
+
+    v16i acc[NIW];
+#pragma unroll
+    for (int t = 0; t < NIW; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0;
+    }
+
+    // does any output channel of this tile have zw' != 0 ?  (workgroup-uniform)
+    int zw_local = 0;
+    if (tid < MT) zw_local = (a.ep[a.OCP + ot * MT + tid] != 0.0f) ? 1 : 0;
+    const bool need_sx = __syncthreads_or(zw_local) != 0;  // also orders the LDS zero fill
+
+    // Activation fetch.  No value is ever masked here: rows outside the image belong to threads
+    // whose LDS writes go to the trash slots, and channels >= IC meet all-zero weights in Wt (prep).
+    uint32_t d[MF_UNITS][16];
+    auto issue_x = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < MF_UNITS; ++u) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ic = c * 32 + u * 16 + i;                 // wave-uniform
+                const int icc = ic < a.IC ? ic : a.IC - 1;
+                if constexpr (X8) {
+                    const uint8_t *plane = xi + (int64_t)icc * HW;  // scalar base
+                    uint32_t v;
+                    __builtin_memcpy(&v, plane + (uint32_t)u_off, 4);  // one (possibly unaligned) global_load_dword
+                    d[u][i] = v;
+                } else {
+                    const int64_t bit = (img_off + (int64_t)icc * HW + u_off) * a.x_bits + (u_sh / 8) * a.x_bits;
+                    const int64_t byte = bit >> 3;
+                    const int64_t bc = byte < lim8 ? byte : lim8;
+                    uint64_t v;
+                    __builtin_memcpy(&v, xi + bc, 8);
+                    v >>= ((int)(bit & 7) + 8 * (int)(byte - bc));
+                    const uint32_t mask = (1u << a.x_bits) - 1u;
+                    uint32_t r = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        r |= ((((uint32_t)(v >> (j * a.x_bits)) & mask) - (uint32_t)cbx) & 0xffu) << (8 * j);
+                    d[u][i] = r;
+                }
+            }
+        }
+    };
+    auto stage_x = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < MF_UNITS; ++u) {
+            if constexpr (X8) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) d[u][i] = (d[u][i] >> u_sh) ^ 0x80808080u;  // u - 128: signed q / unsigned q - 128
+            }
+            uint32_t o[4][4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                transpose4x4(d[u][4 * m], d[u][4 * m + 1], d[u][4 * m + 2], d[u][4 * m + 3],
+                             o[0][m], o[1][m], o[2][m], o[3][m]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = u_lds[j] >= 0 ? u_lds[j] + u * GSZ : trash;
+                Xs[idx] = make_uint4(o[j][0], o[j][1], o[j][2], o[j][3]);
+            }
+            if (need_sx) {
+                // S_x needs sum_ic a_x per input pixel over REAL channels only
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int sum = 0;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const int nv = a.IC - (c * 32 + u * 16 + 4 * m);  // valid channels in this dword
+                        const int ones = nv >= 4 ? 0x01010101 : (nv <= 0 ? 0 : (0x01010101 & ((1 << (8 * nv)) - 1)));
+                        sum = __builtin_amdgcn_sdot4((int)o[j][m], ones, sum, false);
+                    }
+                    if (u_lds[j] >= 0) atomicAdd(&sxp[u_lds[j]], sum);
+                }
+            }
+        }
+    };
+    auto mma_tap = [&](const v4i af, int tapoff) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < NIW; ++t) {
+            const v4i b = *reinterpret_cast<const v4i *>(&Xs[pixidx[t] + tapoff]);
+            acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, b, acc[t], 0, 0, 0);
+        }
+    };
+    // one 32-channel chunk: request A(c) -> X(c) regs into LDS -> barrier -> request X(c+1) -> MFMA
+    auto chunk = [&](int c, auto prefetch) __attribute__((always_inline)) {
+        const int8_t *a_c = a_base + (int64_t)(2 * c) * grp_stride;
+        v4i afr[(KKT > 0) ? KKT : 1];
+        if constexpr (KKT > 0) {
+#pragma unroll
+            for (int tap = 0; tap < KKT; ++tap) afr[tap] = *reinterpret_cast<const v4i *>(a_c + tap * tap_stride + a_voff);
+        } else {
+            afr[0] = *reinterpret_cast<const v4i *>(a_c + a_voff);
+        }
+        stage_x(c);
+        __syncthreads();
+        if constexpr (decltype(prefetch)::value) issue_x(c + 1);
+        if constexpr (KKT > 0) {
+#pragma unroll
+            for (int tap = 0; tap < KKT; ++tap) {
+                constexpr int KW_T = (KKT == 9) ? 3 : 1;
+                mma_tap(afr[tap], (tap / KW_T) * a.IWP + (tap % KW_T));
+            }
+        } else {
+            v4i af = afr[0];
+            for (int tap = 0; tap < KK; ++tap) {
+                const int nxt = tap + 1 < KK ? tap + 1 : tap;
+                const v4i af_next = *reinterpret_cast<const v4i *>(a_c + nxt * tap_stride + a_voff);
+                const int kh = tap / a.KW;
+                mma_tap(af, kh * a.IWP + (tap - kh * a.KW));
+                af = af_next;
+            }
+        }
+        __syncthreads();  // everyone is done reading before the next chunk overwrites the image
+    };
+
+    issue_x(0);
+    for (int c = 0; c < a.NCH - 1; ++c) chunk(c, std::true_type{});
+    chunk(a.NCH - 1, std::false_type{});
+
+    // ---- epilogue -----------------------------------------------------------------------------
+    const float zxp = a.x_zero[0] - zero_shift(a.x_bits, a.x_sign);
+    const bool need_sw = zxp != 0.0f;
+    const int oc_base = ot * MT + wm * 32 + 4 * h;  // + (reg&3) + 8*(reg>>2)
+    float al[16], bi[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int oc = oc_base + (r & 3) + 8 * (r >> 2);
+        al[r] = a.ep[oc];
+        bi[r] = a.ep[2 * a.OCP + oc];
+    }
+    const int64_t OHW = (int64_t)a.OH * a.OW;
+    float *out_n = a.out + (int64_t)n * a.OC * OHW + (int64_t)oh0 * a.OW;
+    const bool full_oc = (ot + 1) * MT <= a.OC;
+
+    if (!need_sx && !need_sw) {
+        // symmetric operands: out = bias + alpha * S_aw.  Store address = wave-uniform row base
+        // (scalar) + one per-lane 32-bit offset: lanes 0-31 are 32 consecutive pixels of row dr,
+        // lanes 32-63 of row dr + 4 -> two full 128-byte lines per store instruction.
+        float *out_w = out_n + (int64_t)(ot * MT + wm * 32) * OHW;          // uniform
+        const uint32_t voff = (uint32_t)(4 * h) * (uint32_t)OHW + (uint32_t)col;
+#pragma unroll
+        for (int t = 0; t < NIW; ++t) {
+            const int q0 = (wn + t * WN) * 32;
+            if (full_oc && q0 + 32 <= NT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float *row = out_w + (int64_t)((r & 3) + 8 * (r >> 2)) * OHW + q0;  // uniform
+                    row[voff] = fmaf(al[r], (float)acc[t][r], bi[r]);
+                }
+            } else {
+                const bool valid = q0 + col < NT;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    float *row = out_w + (int64_t)dr * OHW + q0;
+                    if (valid && oc_base + dr < a.OC) row[voff] = fmaf(al[r], (float)acc[t][r], bi[r]);
+                }
+            }
+        }
+    } else {
+        float zw[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zw[r] = a.ep[a.OCP + oc_base + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+        for (int t = 0; t < NIW; ++t) {
+            const int q = (wn + t * WN) * 32 + col;
+            const bool valid = q < NT;
+            // in-bounds taps of this pixel: the reference skips padded taps (quantconv2d.cu:101)
+            unsigned long long mask = 0;
+            int n_inb = 0, sxs = 0;
+            bool interior = true;
+            {
+                const int r = valid ? q / a.OW : 0, c = valid ? q - r * a.OW : 0;
+                const int ihb = (oh0 + r) * a.stride - a.pad, iwb = c * a.stride - a.pad;
+                const int pbase = pixidx[t] - h * GSZ;
+                for (int tap = 0; tap < KK; ++tap) {
+                    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+                    const bool inb = (ihb + kh) >= 0 && (ihb + kh) < a.H && (iwb + kw) >= 0 && (iwb + kw) < a.W;
+                    if (inb) { mask |= 1ull << tap; ++n_inb; } else interior = false;
+                    if (need_sx) sxs += sxp[pbase + kh * a.IWP + kw];  // zero outside the image
+                }
+            }
+            const float fn = (float)(n_inb * a.IC);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int oc = oc_base + (r & 3) + 8 * (r >> 2);
+                float v = (float)acc[t][r];
+                v = fmaf(-zw[r], (float)sxs, v);
+                if (need_sw) {
+                    const int *wsr = a.ws + (int64_t)oc * (KK + 1);
+                    int sw_sum = wsr[KK];
+                    if (!interior) {
+                        sw_sum = 0;
+                        for (int tap = 0; tap < KK; ++tap)
+                            if ((mask >> tap) & 1ull) sw_sum += wsr[tap];
+                    }
+                    v = fmaf(-zxp, (float)sw_sum, v);
+                    v = fmaf(fn * zxp, zw[r], v);
+                }
+                const float res = fmaf(al[r], v, bi[r]);
+                if (valid && oc < a.OC) out_n[(int64_t)oc * OHW + q] = res;
+            }
+        }
+    }
+}
+
+// launchers, one translation unit per wave layout (qe_conv_mfma_i*.hip)
+void launch_mfma_cfg0(const MfmaArgs &a, int niw, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
+void launch_mfma_cfg1(const MfmaArgs &a, int niw, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
+void launch_mfma_cfg2(const MfmaArgs &a, int niw, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
+
+#define QE_MFMA_LAUNCH(WM, WN, NIW)                                                                       \
+    do {                                                                                                  \
+        if (KK == 1) {                                                                                    \
+            if (x8) hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, NIW, 1, true>), dim3(blocks), dim3(MF_THREADS), lds, s, a);  \
+            else    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, NIW, 1, false>), dim3(blocks), dim3(MF_THREADS), lds, s, a); \
+        } else if (KK == 9 && a.KW == 3) {                                                                \
+            if (x8) hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, NIW, 9, true>), dim3(blocks), dim3(MF_THREADS), lds, s, a);  \
+            else    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, NIW, 9, false>), dim3(blocks), dim3(MF_THREADS), lds, s, a); \
+        } else {                                                                                          \
+            if (x8) hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, NIW, 0, true>), dim3(blocks), dim3(MF_THREADS), lds, s, a);  \
+            else    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, NIW, 0, false>), dim3(blocks), dim3(MF_THREADS), lds, s, a); \
+        }                                                                                                 \
+    } while (0)
+
+}  // namespace qe

@@ -45,10 +45,12 @@ def algorithmic_bytes(layer, N, x_bits=8, w_bits=8, float_input=False):
     return in_b + (n_w * w_bits + 7) // 8 + N * layer.OC * o * o * 4
 
 
-def synth_layer(layer, idx, N, device, x_bits=8, w_bits=8, asymmetric=False, with_bias=True):
+def synth_layer(layer, idx, N, device, x_bits=8, w_bits=8, asymmetric=False, with_bias=True, rank=0):
     """Synthetic operands of one layer: seed 1000+idx; q_w ~ U{qmin..qmax},
     s_w[oc] ~ U(2.5e-4, 7.5e-4), z_w = 0; q_x ~ U{qmin..qmax}, per-tensor s_x = 2e-3, z_x = 0
     (asymmetric: unsigned q_x with z_x = 133.2578 * 2^(bits-8), kernel convention); bias ~ N(0, 0.1).
+    Weights, scales and bias are identical on every rank (replicated); the activations of rank r > 0
+    (its own 256-image shard of the global batch) come from a rank-specific seed.
     Returns integer-valued int16 tensors (to be packed by the engine) plus fp32 parameters."""
     import torch
     g = torch.Generator(device=device)
@@ -58,6 +60,9 @@ def synth_layer(layer, idx, N, device, x_bits=8, w_bits=8, asymmetric=False, wit
                        dtype=torch.int16)
     sw = (torch.rand(layer.OC, generator=g, device=device) * 5e-4 + 2.5e-4).reshape(-1, 1, 1, 1)
     zw = torch.zeros_like(sw)
+    bias = (torch.randn(layer.OC, generator=g, device=device) * 0.1) if with_bias else None
+    if rank:
+        g.manual_seed(1000 + idx + 1000003 * rank)
     if asymmetric:
         qx = torch.randint(0, 1 << x_bits, (N, layer.IC, layer.H, layer.H), generator=g, device=device,
                            dtype=torch.int16)
@@ -70,5 +75,4 @@ def synth_layer(layer, idx, N, device, x_bits=8, w_bits=8, asymmetric=False, wit
         zx = torch.zeros(1, device=device)
         x_sign = True
     sx = torch.full((1,), 2e-3, device=device)
-    bias = (torch.randn(layer.OC, generator=g, device=device) * 0.1) if with_bias else None
     return dict(qx=qx, x_sign=x_sign, sx=sx, zx=zx, qw=qw, w_sign=True, sw=sw, zw=zw, bias=bias)
