@@ -119,6 +119,52 @@ __global__ __launch_bounds__(256) void conv_mfma_prep_kernel(const PrepArgs a)
     }
 }
 
+// prep for the small-IC kernel: Wt[kh][h][oc][16], byte (kw - 4h)*4 + ic; same ep / ws tables.
+__global__ __launch_bounds__(64) void conv_mfma_prep_smallic_kernel(const PrepArgs a, int KH, int KW)
+{
+    __shared__ int s_ws[64];
+    const int oc = blockIdx.x;
+    const int tid = threadIdx.x;
+    s_ws[tid] = 0;
+    __syncthreads();
+    const int cb = code_bias(a.w_bits, a.w_sign);
+    const bool live = oc < a.OC;
+    if (tid < KH * 2) {
+        const int kh = tid >> 1, h = tid & 1;
+        uint32_t v[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int kw = 4 * h + (j >> 2), ic = j & 3;
+            int aw = 0;
+            if (live && kw < KW && ic < a.IC) {
+                const int64_t e = ((int64_t)oc * a.IC + ic) * a.KK + kh * KW + kw;  // quantconv2d.cu:118
+                aw = unpack_code(a.w, e, a.w_bits) - cb;
+                atomicAdd(&s_ws[kh * KW + kw], aw);
+            }
+            v[j >> 2] |= ((uint32_t)aw & 0xffu) << ((j & 3) * 8);
+        }
+        *reinterpret_cast<uint4 *>(a.wt + (((int64_t)kh * 2 + h) * a.OCP + oc) * 16) = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+    if (tid < a.KK) a.ws[oc * (a.KK + 1) + tid] = s_ws[tid];
+    if (tid == 0) {
+        int all = 0;
+        for (int t = 0; t < a.KK; ++t) all += s_ws[t];
+        a.ws[oc * (a.KK + 1) + a.KK] = all;
+        float alpha = 0.0f, zwp = 0.0f, b = 0.0f;
+        if (live) {
+            const float sw = a.w_per_tensor ? a.w_scale[0] : a.w_scale[oc];
+            const float zw = a.w_per_tensor ? a.w_zero[0] : a.w_zero[oc];
+            alpha = a.x_scale[0] * sw;
+            zwp = zw - zero_shift(a.w_bits, a.w_sign);
+            b = a.bias ? a.bias[oc] : 0.0f;
+        }
+        a.ep[oc] = alpha;
+        a.ep[a.OCP + oc] = zwp;
+        a.ep[2 * a.OCP + oc] = b;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -127,6 +173,7 @@ struct MfmaPlan {
     int cfg = 0;       // 0: 4x1 waves (MT 128), 1: 2x2 (MT 64), 2: 1x4 (MT 32)
     int MT = 0, OCP = 0, NCH = 0, NG = 0, KK = 0, OH = 0, OW = 0;
     int TH = 0, ni = 0, niw = 0, IHT = 0, IWP = 0, ROWMUL = 1, COLMUL = 1;
+    bool smallic = false;
     size_t lds = 0;
     size_t wt_bytes = 0, ep_off = 0, ws_off = 0, total = 0;
 };
@@ -137,7 +184,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static const int kNiw[3][3] = {{7, 4, 2}, {4, 2, 1}, {2, 1, 0}};
 static const int kWN[3] = {1, 2, 4};
 
-static MfmaPlan make_plan(const qe_conv_shape *sh)
+static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits)
 {
     MfmaPlan p;
     p.OH = (sh->H + 2 * sh->padding - sh->KH) / sh->stride + 1;
@@ -155,27 +202,45 @@ static MfmaPlan make_plan(const qe_conv_shape *sh)
     const int max_tiles = kNiw[p.cfg][0] * kWN[p.cfg];
     if (p.KK > 64 || p.OW > 32 * max_tiles) return p;
     p.OCP = (sh->OC + p.MT - 1) / p.MT * p.MT;
-    p.NCH = (sh->IC + 31) / 32;
-    p.NG = 2 * p.NCH;
-    p.ROWMUL = (sh->KH == 1) ? sh->stride : 1;   // 1xK strided: only every stride-th row is ever read
-    p.COLMUL = (sh->KW == 1) ? sh->stride : 1;
     const int NQ = (sh->W + 3) / 4;
-    int TH = std::min(p.OH, (32 * max_tiles) / p.OW);
-    for (; TH >= 1; --TH) {
-        const int IHT = (p.ROWMUL > 1) ? TH : (TH - 1) * sh->stride + sh->KH;
-        const int IWP = (p.COLMUL > 1) ? p.OW : (p.OW - 1) * sh->stride + sh->KW;
-        const size_t lds = ((size_t)2 * IHT * IWP + MF_TRASH) * 16 + (size_t)IHT * IWP * 4;
-        if (lds <= (size_t)MF_MAX_LDS && IHT * NQ <= MF_THREADS) {
-            p.TH = TH; p.IHT = IHT; p.IWP = IWP; p.lds = lds;
-            break;
+    p.smallic = sh->IC <= 4 && sh->KW <= 8 && sh->KH <= 8 && x_bits == 8;
+    if (p.smallic) {
+        // stem layout: K = (kh) x [kw 0..7][ic 0..3]; the whole (tiny) channel depth is one stage
+        p.NCH = 1;
+        p.NG = 2;
+        p.niw = kNiw[p.cfg][0];
+        int TH = std::min(p.OH, (32 * max_tiles) / p.OW);
+        for (; TH >= 1; --TH) {
+            const int IHT = (TH - 1) * sh->stride + sh->KH;
+            const int IWP = (p.OW - 1) * sh->stride + 8;
+            const size_t lds = ((size_t)IHT * IWP * 2 + MF_TRASH) * 4;
+            if (lds <= (size_t)MF_MAX_LDS) { p.TH = TH; p.IHT = IHT; p.IWP = IWP; p.lds = lds; break; }
         }
+        if (p.TH == 0) return p;
+        p.ni = (p.TH * p.OW + 31) / 32;
+        p.wt_bytes = (size_t)sh->KH * 2 * p.OCP * 16;
+    } else {
+        p.NCH = (sh->IC + 31) / 32;
+        p.NG = 2 * p.NCH;
+        p.ROWMUL = (sh->KH == 1) ? sh->stride : 1;   // 1xK strided: only every stride-th row is ever read
+        p.COLMUL = (sh->KW == 1) ? sh->stride : 1;
+        int TH = std::min(p.OH, (32 * max_tiles) / p.OW);
+        for (; TH >= 1; --TH) {
+            const int IHT = (p.ROWMUL > 1) ? TH : (TH - 1) * sh->stride + sh->KH;
+            const int IWP = (p.COLMUL > 1) ? p.OW : (p.OW - 1) * sh->stride + sh->KW;
+            const size_t lds = ((size_t)2 * IHT * IWP + MF_TRASH) * 16 + (size_t)IHT * IWP * 4;
+            if (lds <= (size_t)MF_MAX_LDS && IHT * NQ <= MF_THREADS) {
+                p.TH = TH; p.IHT = IHT; p.IWP = IWP; p.lds = lds;
+                break;
+            }
+        }
+        if (p.TH == 0) return p;
+        p.ni = (p.TH * p.OW + 31) / 32;
+        p.niw = kNiw[p.cfg][0];
+        for (int i = 0; i < 3; ++i)
+            if (kNiw[p.cfg][i] > 0 && kNiw[p.cfg][i] * kWN[p.cfg] >= p.ni) p.niw = kNiw[p.cfg][i];
+        p.wt_bytes = (size_t)p.KK * p.NG * p.OCP * 16;
     }
-    if (p.TH == 0) return p;
-    p.ni = (p.TH * p.OW + 31) / 32;
-    p.niw = kNiw[p.cfg][0];
-    for (int i = 0; i < 3; ++i)
-        if (kNiw[p.cfg][i] > 0 && kNiw[p.cfg][i] * kWN[p.cfg] >= p.ni) p.niw = kNiw[p.cfg][i];
-    p.wt_bytes = (size_t)p.KK * p.NG * p.OCP * 16;
     p.ep_off = align_up(p.wt_bytes, 256);
     p.ws_off = align_up(p.ep_off + (size_t)3 * p.OCP * sizeof(float), 256);
     p.total = align_up(p.ws_off + (size_t)p.OCP * (p.KK + 1) * sizeof(int), 256);
@@ -187,19 +252,19 @@ bool mfma_conv_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qp
 {
     (void)w;
     if (x->n_param != 1) return false;  // per-channel activation scale cannot leave the K sum
-    return make_plan(sh).ok;
+    return make_plan(sh, x->n_bits).ok;
 }
 
-size_t mfma_conv_workspace_bytes(const qe_conv_shape *sh)
+size_t mfma_conv_workspace_bytes(const qe_conv_shape *sh, int x_bits)
 {
-    const MfmaPlan p = make_plan(sh);
+    const MfmaPlan p = make_plan(sh, x_bits);
     return p.ok ? p.total : 0;
 }
 
 int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh,
                      float *out, void *workspace, size_t workspace_bytes, hipStream_t s)
 {
-    const MfmaPlan p = make_plan(sh);
+    const MfmaPlan p = make_plan(sh, x->n_bits);
     if (!p.ok) return QE_ERR_UNSUPPORTED;
     if (workspace == nullptr || workspace_bytes < p.total) return QE_ERR_WORKSPACE;
     if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return QE_ERR_ARG;
@@ -212,7 +277,10 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     pa.wt = reinterpret_cast<int8_t *>(wsp);
     pa.ep = reinterpret_cast<float *>(wsp + p.ep_off);
     pa.ws = reinterpret_cast<int *>(wsp + p.ws_off);
-    hipLaunchKernelGGL(conv_mfma_prep_kernel, dim3(p.OCP), dim3(256), 0, s, pa);
+    if (p.smallic)
+        hipLaunchKernelGGL(conv_mfma_prep_smallic_kernel, dim3(p.OCP), dim3(64), 0, s, pa, (int)sh->KH, (int)sh->KW);
+    else
+        hipLaunchKernelGGL(conv_mfma_prep_kernel, dim3(p.OCP), dim3(256), 0, s, pa);
     QE_LAUNCH_CHECK();
 
     MfmaArgs a;
@@ -232,6 +300,11 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     const int64_t blocks = groups * 8 * a.n_oc_tiles;
     if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
     const bool x8 = x->n_bits == 8;
+    if (p.smallic) {
+        launch_mfma_smallic(a, p.cfg, (unsigned)blocks, p.lds, s);
+        QE_LAUNCH_CHECK();
+        return QE_OK;
+    }
     switch (p.cfg) {
         case 0: launch_mfma_cfg0(a, p.niw, p.KK, x8, (unsigned)blocks, p.lds, s); break;
         case 1: launch_mfma_cfg1(a, p.niw, p.KK, x8, (unsigned)blocks, p.lds, s); break;

@@ -89,6 +89,101 @@ __device__ __forceinline__ void transpose4x4(uint32_t d0, uint32_t d1, uint32_t 
     o3 = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Shared epilogue: D (rows = output channel, cols = pixel on the lane) -> fp32 NCHW.
+//   out = bias + alpha * (S_aw - zw' S_x - zx' S_w + N_inb zx' zw')      (see qe_conv_mfma.hip)
+// ---------------------------------------------------------------------------------------------
+template <int WM, int WN, int NIW>
+__device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW], const int (&sxs)[NIW],
+                                              const bool need_sx, const int n, const int ot, const int oh0,
+                                              const int NT, const int wm, const int wn, const int col,
+                                              const int h, const int KK)
+{
+    constexpr int MT = 32 * WM;
+    const float zxp = a.x_zero[0] - zero_shift(a.x_bits, a.x_sign);
+    const bool need_sw = zxp != 0.0f;
+    const int oc_base = ot * MT + wm * 32 + 4 * h;  // + (reg&3) + 8*(reg>>2)
+    float al[16], bi[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int oc = oc_base + (r & 3) + 8 * (r >> 2);
+        al[r] = a.ep[oc];
+        bi[r] = a.ep[2 * a.OCP + oc];
+    }
+    const int64_t OHW = (int64_t)a.OH * a.OW;
+    float *out_n = a.out + (int64_t)n * a.OC * OHW + (int64_t)oh0 * a.OW;
+    const bool full_oc = (ot + 1) * MT <= a.OC;
+
+    if (!need_sx && !need_sw) {
+        // symmetric operands: out = bias + alpha * S_aw.  Store address = wave-uniform row base
+        // (scalar) + one per-lane 32-bit offset: lanes 0-31 are 32 consecutive pixels of row dr,
+        // lanes 32-63 of row dr + 4 -> two full 128-byte lines per store instruction.
+        float *out_w = out_n + (int64_t)(ot * MT + wm * 32) * OHW;          // uniform
+        const uint32_t voff = (uint32_t)(4 * h) * (uint32_t)OHW + (uint32_t)col;
+#pragma unroll
+        for (int t = 0; t < NIW; ++t) {
+            const int q0 = (wn + t * WN) * 32;
+            if (full_oc && q0 + 32 <= NT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float *row = out_w + (int64_t)((r & 3) + 8 * (r >> 2)) * OHW + q0;  // uniform
+                    row[voff] = fmaf(al[r], (float)acc[t][r], bi[r]);
+                }
+            } else {
+                const bool valid = q0 + col < NT;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    float *row = out_w + (int64_t)dr * OHW + q0;
+                    if (valid && oc_base + dr < a.OC) row[voff] = fmaf(al[r], (float)acc[t][r], bi[r]);
+                }
+            }
+        }
+    } else {
+        float zw[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zw[r] = a.ep[a.OCP + oc_base + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+        for (int t = 0; t < NIW; ++t) {
+            const int q = (wn + t * WN) * 32 + col;
+            const bool valid = q < NT;
+            // in-bounds taps of this pixel: the reference skips padded taps (quantconv2d.cu:101)
+            unsigned long long mask = 0;
+            int n_inb = 0;
+            bool interior = true;
+            {
+                const int r = valid ? q / a.OW : 0, c = valid ? q - r * a.OW : 0;
+                const int ihb = (oh0 + r) * a.stride - a.pad, iwb = c * a.stride - a.pad;
+                for (int tap = 0; tap < KK; ++tap) {
+                    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+                    const bool inb = (ihb + kh) >= 0 && (ihb + kh) < a.H && (iwb + kw) >= 0 && (iwb + kw) < a.W;
+                    if (inb) { mask |= 1ull << tap; ++n_inb; } else interior = false;
+                }
+            }
+            const float fn = (float)(n_inb * a.IC);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int oc = oc_base + (r & 3) + 8 * (r >> 2);
+                float v = (float)acc[t][r];
+                v = fmaf(-zw[r], (float)sxs[t], v);
+                if (need_sw) {
+                    const int *wsr = a.ws + (int64_t)oc * (KK + 1);
+                    int sw_sum = wsr[KK];
+                    if (!interior) {
+                        sw_sum = 0;
+                        for (int tap = 0; tap < KK; ++tap)
+                            if ((mask >> tap) & 1ull) sw_sum += wsr[tap];
+                    }
+                    v = fmaf(-zxp, (float)sw_sum, v);
+                    v = fmaf(fn * zxp, zw[r], v);
+                }
+                const float res = fmaf(al[r], v, bi[r]);
+                if (valid && oc < a.OC) out_n[(int64_t)oc * OHW + q] = res;
+            }
+        }
+    }
+}
+
 // WM x WN waves over (oc strips, pixel column tiles); NIW column tiles per wave; KKT = taps known
 // at compile time (1, 9 = 3x3) or 0 for a runtime tap loop; X8 = 8-bit activations.
 template <int WM, int WN, int NIW, int KKT, bool X8>
@@ -294,96 +389,158 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs
     chunk(a.NCH - 1, std::false_type{});
 
     // ---- epilogue -----------------------------------------------------------------------------
-    const float zxp = a.x_zero[0] - zero_shift(a.x_bits, a.x_sign);
-    const bool need_sw = zxp != 0.0f;
-    const int oc_base = ot * MT + wm * 32 + 4 * h;  // + (reg&3) + 8*(reg>>2)
-    float al[16], bi[16];
+    int sxs[NIW];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int oc = oc_base + (r & 3) + 8 * (r >> 2);
-        al[r] = a.ep[oc];
-        bi[r] = a.ep[2 * a.OCP + oc];
+    for (int t = 0; t < NIW; ++t) {
+        sxs[t] = 0;
+        if (need_sx) {
+            const int pbase = pixidx[t] - h * GSZ;
+            for (int tap = 0; tap < KK; ++tap) {
+                const int kh = tap / a.KW;
+                sxs[t] += sxp[pbase + kh * a.IWP + (tap - kh * a.KW)];  // zero outside the image
+            }
+        }
     }
-    const int64_t OHW = (int64_t)a.OH * a.OW;
-    float *out_n = a.out + (int64_t)n * a.OC * OHW + (int64_t)oh0 * a.OW;
-    const bool full_oc = (ot + 1) * MT <= a.OC;
+    mfma_epilogue<WM, WN, NIW>(a, acc, sxs, need_sx, n, ot, oh0, NT, wm, wn, col, h, KK);
+}
 
-    if (!need_sx && !need_sw) {
-        // symmetric operands: out = bias + alpha * S_aw.  Store address = wave-uniform row base
-        // (scalar) + one per-lane 32-bit offset: lanes 0-31 are 32 consecutive pixels of row dr,
-        // lanes 32-63 of row dr + 4 -> two full 128-byte lines per store instruction.
-        float *out_w = out_n + (int64_t)(ot * MT + wm * 32) * OHW;          // uniform
-        const uint32_t voff = (uint32_t)(4 * h) * (uint32_t)OHW + (uint32_t)col;
+// ---------------------------------------------------------------------------------------------
+// Small-IC variant (IC <= 4, KW <= 8, 8-bit activations): the stem convolution (3 -> 64, 7x7/2).
+// Padding 3 channels to a 32-channel chunk would waste 10x the MFMA work and LDS, so K is laid out
+// as (kh) x [kw 0..7][ic 0..3]: one 32-deep MFMA step per kernel row.  LDS holds the halo tile
+// as one dword per pixel [c0 c1 c2 c3]; the B fragment of lane (pixel, half h) is the 16 bytes of
+// 4 consecutive pixels starting at column ow*stride + 4h of row oh*stride + kh.
+//   Wt layout here: [KH][2][OCP][16], byte (kw - 4h)*4 + ic.
+// ---------------------------------------------------------------------------------------------
+template <int WM, int WN, int NIW>
+__global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_smallic_kernel(const MfmaArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *Xs = reinterpret_cast<uint32_t *>(smem);
+
+    constexpr int MT = 32 * WM;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int col = lane & 31, h = lane >> 5;
+
+    const int bid = blockIdx.x;
+    const int grp_sz = 8 * a.n_oc_tiles;
+    const int grp = bid / grp_sz, rem = bid - grp * grp_sz;
+    const int pt = grp * 8 + (rem & 7);
+    const int ot = rem >> 3;
+    if (pt >= a.n_pix_tiles) return;
+
+    const int n = pt / a.tiles_h;
+    const int oh0 = (pt - n * a.tiles_h) * a.TH;
+    const int th = min(a.TH, a.OH - oh0);
+    const int NT = th * a.OW;
+    const int ih0 = oh0 * a.stride - a.pad;
+    const int GSZ = a.IHT * a.IWP;       // pixels (dwords) in the halo image
+    const int KK = a.KH * a.KW;
+    int *sxp = reinterpret_cast<int *>(Xs + GSZ + MF_TRASH);
+    const int trash = GSZ + lane;
+
+    for (int i = tid; i < GSZ; i += MF_THREADS) { Xs[i] = 0; sxp[i] = 0; }
+
+    int zw_local = 0;
+    if (tid < MT) zw_local = (a.ep[a.OCP + ot * MT + tid] != 0.0f) ? 1 : 0;
+    const bool need_sx = __syncthreads_or(zw_local) != 0;
+
+    // weight fragments of all kernel rows (L2 hits), requested before the activation loads
+    v4i afr[8];
+    {
+        const int8_t *a_base = a.wt + (int64_t)(ot * MT + wm * 32) * 16;
+        const uint32_t a_voff = (uint32_t)(h * a.OCP + col) * 16u;
 #pragma unroll
-        for (int t = 0; t < NIW; ++t) {
-            const int q0 = (wn + t * WN) * 32;
-            if (full_oc && q0 + 32 <= NT) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float *row = out_w + (int64_t)((r & 3) + 8 * (r >> 2)) * OHW + q0;  // uniform
-                    row[voff] = fmaf(al[r], (float)acc[t][r], bi[r]);
-                }
-            } else {
-                const bool valid = q0 + col < NT;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dr = (r & 3) + 8 * (r >> 2);
-                    float *row = out_w + (int64_t)dr * OHW + q0;
-                    if (valid && oc_base + dr < a.OC) row[voff] = fmaf(al[r], (float)acc[t][r], bi[r]);
-                }
-            }
+        for (int kh = 0; kh < 8; ++kh) {
+            const int khc = kh < a.KH ? kh : a.KH - 1;
+            afr[kh] = *reinterpret_cast<const v4i *>(a_base + (int64_t)khc * 2 * a.OCP * 16 + a_voff);
         }
-    } else {
-        float zw[16];
+    }
+
+    // ---- stage the halo tile: thread <-> (row l, quad iq), IC dwords -> 4 pixel dwords ----------
+    const int NQ = (a.W + 3) >> 2;
+    const int HW = a.H * a.W;
+    const uint8_t *xi = a.x + (int64_t)n * a.IC * HW;
+    const int ones = a.IC >= 4 ? 0x01010101 : (0x01010101 & ((1 << (8 * a.IC)) - 1));
+    for (int uid = tid; uid < a.IHT * NQ; uid += MF_THREADS) {
+        const int l = uid / NQ, iq = uid - l * NQ;
+        const int ih = ih0 + l;
+        const bool ok = ih >= 0 && ih < a.H;
+        int iw0 = 4 * iq, sh = 0;
+        if (iw0 + 4 > a.W) { sh = 8 * (iw0 + 4 - a.W); iw0 = a.W - 4; }
+        const uint32_t off = ok ? (uint32_t)(ih * a.W + iw0) : 0u;
+        uint32_t dch[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) zw[r] = a.ep[a.OCP + oc_base + (r & 3) + 8 * (r >> 2)];
+        for (int i = 0; i < 4; ++i) {
+            const int icc = i < a.IC ? i : a.IC - 1;       // uniform
+            uint32_t v;
+            __builtin_memcpy(&v, xi + (int64_t)icc * HW + off, 4);
+            dch[i] = (i < a.IC) ? ((v >> sh) ^ 0x80808080u) : 0u;  // uniform select; padded channel = 0
+        }
+        uint32_t o0, o1, o2, o3;
+        transpose4x4(dch[0], dch[1], dch[2], dch[3], o0, o1, o2, o3);
+        const uint32_t o[4] = {o0, o1, o2, o3};
 #pragma unroll
-        for (int t = 0; t < NIW; ++t) {
-            const int q = (wn + t * WN) * 32 + col;
-            const bool valid = q < NT;
-            // in-bounds taps of this pixel: the reference skips padded taps (quantconv2d.cu:101)
-            unsigned long long mask = 0;
-            int n_inb = 0, sxs = 0;
-            bool interior = true;
-            {
-                const int r = valid ? q / a.OW : 0, c = valid ? q - r * a.OW : 0;
-                const int ihb = (oh0 + r) * a.stride - a.pad, iwb = c * a.stride - a.pad;
-                const int pbase = pixidx[t] - h * GSZ;
-                for (int tap = 0; tap < KK; ++tap) {
-                    const int kh = tap / a.KW, kw = tap - kh * a.KW;
-                    const bool inb = (ihb + kh) >= 0 && (ihb + kh) < a.H && (iwb + kw) >= 0 && (iwb + kw) < a.W;
-                    if (inb) { mask |= 1ull << tap; ++n_inb; } else interior = false;
-                    if (need_sx) sxs += sxp[pbase + kh * a.IWP + kw];  // zero outside the image
-                }
-            }
-            const float fn = (float)(n_inb * a.IC);
+        for (int j = 0; j < 4; ++j) {
+            const int iw = 4 * iq + j;
+            const int cl = iw + a.pad;
+            const bool pok = ok && iw < a.W && cl < a.IWP;
+            const int idx = pok ? l * a.IWP + cl : trash;
+            Xs[idx] = o[j];
+            if (need_sx && pok) sxp[idx] = __builtin_amdgcn_sdot4((int)o[j], ones, 0, false);
+        }
+    }
+    __syncthreads();
+
+    int pixidx[NIW];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int oc = oc_base + (r & 3) + 8 * (r >> 2);
-                float v = (float)acc[t][r];
-                v = fmaf(-zw[r], (float)sxs, v);
-                if (need_sw) {
-                    const int *wsr = a.ws + (int64_t)oc * (KK + 1);
-                    int sw_sum = wsr[KK];
-                    if (!interior) {
-                        sw_sum = 0;
-                        for (int tap = 0; tap < KK; ++tap)
-                            if ((mask >> tap) & 1ull) sw_sum += wsr[tap];
-                    }
-                    v = fmaf(-zxp, (float)sw_sum, v);
-                    v = fmaf(fn * zxp, zw[r], v);
-                }
-                const float res = fmaf(al[r], v, bi[r]);
-                if (valid && oc < a.OC) out_n[(int64_t)oc * OHW + q] = res;
+    for (int t = 0; t < NIW; ++t) {
+        const int q = (wn + t * WN) * 32 + col;
+        const int r = q / a.OW, c = q - r * a.OW;
+        pixidx[t] = (q < NT) ? (r * a.stride) * a.IWP + c * a.stride : 0;
+    }
+
+    v16i acc[NIW];
+#pragma unroll
+    for (int t = 0; t < NIW; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0;
+    }
+#pragma unroll
+    for (int kh = 0; kh < 8; ++kh) {
+        if (kh < a.KH) {
+#pragma unroll
+            for (int t = 0; t < NIW; ++t) {
+                const uint32_t *bp = &Xs[pixidx[t] + kh * a.IWP + 4 * h];
+                v4i b;
+                b[0] = (int)bp[0]; b[1] = (int)bp[1]; b[2] = (int)bp[2]; b[3] = (int)bp[3];
+                acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[kh], b, acc[t], 0, 0, 0);
             }
         }
     }
+
+    int sxs[NIW];
+#pragma unroll
+    for (int t = 0; t < NIW; ++t) {
+        sxs[t] = 0;
+        if (need_sx) {
+            for (int tap = 0; tap < KK; ++tap) {
+                const int kh = tap / a.KW;
+                sxs[t] += sxp[pixidx[t] + kh * a.IWP + (tap - kh * a.KW)];
+            }
+        }
+    }
+    mfma_epilogue<WM, WN, NIW>(a, acc, sxs, need_sx, n, ot, oh0, NT, wm, wn, col, h, KK);
 }
 
 // launchers, one translation unit per wave layout (qe_conv_mfma_i*.hip)
 void launch_mfma_cfg0(const MfmaArgs &a, int niw, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_cfg1(const MfmaArgs &a, int niw, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_cfg2(const MfmaArgs &a, int niw, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
+void launch_mfma_smallic(const MfmaArgs &a, int cfg, unsigned blocks, size_t lds, hipStream_t s);
 
 #define QE_MFMA_LAUNCH(WM, WN, NIW)                                                                       \
     do {                                                                                                  \
