@@ -174,6 +174,7 @@ struct MfmaPlan {
     int MT = 0, OCP = 0, NCH = 0, NG = 0, KK = 0, OH = 0, OW = 0;
     int TH = 0, ni = 0, niw = 0, IHT = 0, IWP = 0, ROWMUL = 1, COLMUL = 1;
     bool smallic = false;
+    int GI = 1, NS = 1;
     size_t lds = 0;
     size_t wt_bytes = 0, ep_off = 0, ws_off = 0, total = 0;
 };
@@ -221,21 +222,37 @@ static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits)
         p.wt_bytes = (size_t)sh->KH * 2 * p.OCP * 16;
     } else {
         p.NCH = (sh->IC + 31) / 32;
-        p.NG = 2 * p.NCH;
         p.ROWMUL = (sh->KH == 1) ? sh->stride : 1;   // 1xK strided: only every stride-th row is ever read
         p.COLMUL = (sh->KW == 1) ? sh->stride : 1;
-        int TH = std::min(p.OH, (32 * max_tiles) / p.OW);
-        for (; TH >= 1; --TH) {
+        const int max_px = 32 * max_tiles;
+        // small feature maps (7x7): several whole images per tile, so a weight fragment and a
+        // barrier pair are amortised over 7 column tiles instead of 2
+        if (p.OH * p.OW <= max_px / 2) p.GI = std::max(1, std::min((int)sh->N, max_px / (p.OH * p.OW)));
+        int TH = (p.GI > 1) ? p.OH : std::min(p.OH, max_px / p.OW);
+        for (;;) {
             const int IHT = (p.ROWMUL > 1) ? TH : (TH - 1) * sh->stride + sh->KH;
             const int IWP = (p.COLMUL > 1) ? p.OW : (p.OW - 1) * sh->stride + sh->KW;
-            const size_t lds = ((size_t)2 * IHT * IWP + MF_TRASH) * 16 + (size_t)IHT * IWP * 4;
-            if (lds <= (size_t)MF_MAX_LDS && IHT * NQ <= MF_THREADS) {
-                p.TH = TH; p.IHT = IHT; p.IWP = IWP; p.lds = lds;
+            const int units = p.GI * IHT * NQ;
+            // chunks per stage: as many as the idle staging threads and LDS allow (1x1, 8-bit only)
+            int ns = 1;
+            if (p.KK == 1 && x_bits == 8) {
+                for (int cand = 4; cand > 1; cand >>= 1) {
+                    const size_t l = ((size_t)2 * cand * p.GI * IHT * IWP + MF_TRASH) * 16 + (size_t)p.GI * IHT * IWP * 4;
+                    if (cand <= p.NCH && units * cand <= MF_THREADS && l <= (size_t)MF_MAX_LDS) { ns = cand; break; }
+                }
+            }
+            const size_t lds = ((size_t)2 * ns * p.GI * IHT * IWP + MF_TRASH) * 16 + (size_t)p.GI * IHT * IWP * 4;
+            if (lds <= (size_t)MF_MAX_LDS && units <= MF_THREADS) {
+                p.TH = TH; p.IHT = IHT; p.IWP = IWP; p.lds = lds; p.NS = ns;
                 break;
             }
+            if (p.GI > 1) { --p.GI; continue; }
+            if (--TH < 1) break;
         }
         if (p.TH == 0) return p;
-        p.ni = (p.TH * p.OW + 31) / 32;
+        p.NCH = (p.NCH + p.NS - 1) / p.NS * p.NS;   // padded chunks carry zero weights
+        p.NG = 2 * p.NCH;
+        p.ni = (p.GI * p.TH * p.OW + 31) / 32;
         p.niw = kNiw[p.cfg][0];
         for (int i = 0; i < 3; ++i)
             if (kNiw[p.cfg][i] > 0 && kNiw[p.cfg][i] * kWN[p.cfg] >= p.ni) p.niw = kNiw[p.cfg][i];
@@ -292,7 +309,8 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     a.stride = sh->stride; a.pad = sh->padding; a.OH = p.OH; a.OW = p.OW;
     a.OCP = p.OCP; a.NG = p.NG; a.NCH = p.NCH;
     a.TH = p.TH; a.tiles_h = (p.OH + p.TH - 1) / p.TH;
-    a.n_pix_tiles = sh->N * a.tiles_h;
+    a.GI = p.GI;
+    a.n_pix_tiles = ((sh->N + p.GI - 1) / p.GI) * a.tiles_h;
     a.n_oc_tiles = p.OCP / p.MT;
     a.IHT = p.IHT; a.IWP = p.IWP; a.ROWMUL = p.ROWMUL; a.COLMUL = p.COLMUL; a.ni = p.ni;
 
@@ -306,9 +324,9 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
         return QE_OK;
     }
     switch (p.cfg) {
-        case 0: launch_mfma_cfg0(a, p.niw, p.KK, x8, (unsigned)blocks, p.lds, s); break;
-        case 1: launch_mfma_cfg1(a, p.niw, p.KK, x8, (unsigned)blocks, p.lds, s); break;
-        default: launch_mfma_cfg2(a, p.niw, p.KK, x8, (unsigned)blocks, p.lds, s); break;
+        case 0: launch_mfma_cfg0(a, p.niw, p.NS, p.KK, x8, (unsigned)blocks, p.lds, s); break;
+        case 1: launch_mfma_cfg1(a, p.niw, p.NS, p.KK, x8, (unsigned)blocks, p.lds, s); break;
+        default: launch_mfma_cfg2(a, p.niw, p.NS, p.KK, x8, (unsigned)blocks, p.lds, s); break;
     }
     QE_LAUNCH_CHECK();
     return QE_OK;

@@ -3,7 +3,7 @@
 
 namespace qe {
 
-void launch_mfma_cfg1(const MfmaArgs &a, int niw, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s)
+void launch_mfma_cfg1(const MfmaArgs &a, int niw, int ns, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s)
 {
     switch (niw) {
         case 4: QE_MFMA_LAUNCH(2, 2, 4); break;

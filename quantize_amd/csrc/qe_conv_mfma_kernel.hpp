@@ -30,6 +30,7 @@ struct MfmaArgs {
     int OCP, NG, NCH;          // padded oc, 16-channel groups (even), 32-channel chunks
     int TH, tiles_h, n_pix_tiles, n_oc_tiles;
     int IHT, IWP, ROWMUL, COLMUL, ni;
+    int GI;                    // whole images per pixel tile (> 1 only for small feature maps, TH == OH)
 };
 
 // stored code u -> MFMA operand a = q - d = u - c, c = off (signed) | 128 (unsigned 8-bit) | 0
@@ -92,12 +93,19 @@ __device__ __forceinline__ void transpose4x4(uint32_t d0, uint32_t d1, uint32_t 
 // ---------------------------------------------------------------------------------------------
 // Shared epilogue: D (rows = output channel, cols = pixel on the lane) -> fp32 NCHW.
 //   out = bias + alpha * (S_aw - zw' S_x - zx' S_w + N_inb zx' zw')      (see qe_conv_mfma.hip)
+// A pixel tile is GI images x th rows x OW columns; column q of the tile is image q / OHWt.
 // ---------------------------------------------------------------------------------------------
+struct TileGeom {
+    int n0;      // first image of the tile
+    int oh0;     // first output row
+    int OHWt;    // pixels per image inside the tile (th * OW)
+    int NT;      // valid columns (images that exist x OHWt)
+};
+
 template <int WM, int WN, int NIW>
 __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW], const int (&sxs)[NIW],
-                                              const bool need_sx, const int n, const int ot, const int oh0,
-                                              const int NT, const int wm, const int wn, const int col,
-                                              const int h, const int KK)
+                                              const bool need_sx, const TileGeom g, const int ot,
+                                              const int wm, const int wn, const int col, const int h, const int KK)
 {
     constexpr int MT = 32 * WM;
     const float zxp = a.x_zero[0] - zero_shift(a.x_bits, a.x_sign);
@@ -110,32 +118,42 @@ __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW
         al[r] = a.ep[oc];
         bi[r] = a.ep[2 * a.OCP + oc];
     }
-    const int64_t OHW = (int64_t)a.OH * a.OW;
-    float *out_n = a.out + (int64_t)n * a.OC * OHW + (int64_t)oh0 * a.OW;
+    const int OHW = a.OH * a.OW;
     const bool full_oc = (ot + 1) * MT <= a.OC;
+    // wave-uniform base: image n0, first channel of the wave's 32-row strip, first row of the tile
+    float *out_w = a.out + ((int64_t)g.n0 * a.OC + ot * MT + wm * 32) * OHW + (int64_t)g.oh0 * a.OW;
+
+    // per-lane element offset of column q: image gi of the tile, pixel rq inside it, rows 4h apart
+    uint32_t voff[NIW];
+    bool valid[NIW];
+#pragma unroll
+    for (int t = 0; t < NIW; ++t) {
+        const int q = (wn + t * WN) * 32 + col;
+        const int gi = (a.GI > 1) ? q / g.OHWt : 0;
+        const int rq = q - gi * g.OHWt;
+        valid[t] = q < g.NT;
+        voff[t] = valid[t] ? (uint32_t)(gi * a.OC + 4 * h) * (uint32_t)OHW + (uint32_t)rq : 0u;
+    }
 
     if (!need_sx && !need_sw) {
         // symmetric operands: out = bias + alpha * S_aw.  Store address = wave-uniform row base
         // (scalar) + one per-lane 32-bit offset: lanes 0-31 are 32 consecutive pixels of row dr,
         // lanes 32-63 of row dr + 4 -> two full 128-byte lines per store instruction.
-        float *out_w = out_n + (int64_t)(ot * MT + wm * 32) * OHW;          // uniform
-        const uint32_t voff = (uint32_t)(4 * h) * (uint32_t)OHW + (uint32_t)col;
 #pragma unroll
         for (int t = 0; t < NIW; ++t) {
             const int q0 = (wn + t * WN) * 32;
-            if (full_oc && q0 + 32 <= NT) {
+            if (full_oc && q0 + 32 <= g.NT) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float *row = out_w + (int64_t)((r & 3) + 8 * (r >> 2)) * OHW + q0;  // uniform
-                    row[voff] = fmaf(al[r], (float)acc[t][r], bi[r]);
+                    float *row = out_w + (int64_t)((r & 3) + 8 * (r >> 2)) * OHW;  // uniform
+                    row[voff[t]] = fmaf(al[r], (float)acc[t][r], bi[r]);
                 }
             } else {
-                const bool valid = q0 + col < NT;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int dr = (r & 3) + 8 * (r >> 2);
-                    float *row = out_w + (int64_t)dr * OHW + q0;
-                    if (valid && oc_base + dr < a.OC) row[voff] = fmaf(al[r], (float)acc[t][r], bi[r]);
+                    float *row = out_w + (int64_t)dr * OHW;
+                    if (valid[t] && oc_base + dr < a.OC) row[voff[t]] = fmaf(al[r], (float)acc[t][r], bi[r]);
                 }
             }
         }
@@ -146,14 +164,15 @@ __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW
 #pragma unroll
         for (int t = 0; t < NIW; ++t) {
             const int q = (wn + t * WN) * 32 + col;
-            const bool valid = q < NT;
             // in-bounds taps of this pixel: the reference skips padded taps (quantconv2d.cu:101)
             unsigned long long mask = 0;
             int n_inb = 0;
             bool interior = true;
             {
-                const int r = valid ? q / a.OW : 0, c = valid ? q - r * a.OW : 0;
-                const int ihb = (oh0 + r) * a.stride - a.pad, iwb = c * a.stride - a.pad;
+                const int gi = valid[t] ? q / g.OHWt : 0;
+                const int rq = valid[t] ? q - gi * g.OHWt : 0;
+                const int r = rq / a.OW, c = rq - r * a.OW;
+                const int ihb = (g.oh0 + r) * a.stride - a.pad, iwb = c * a.stride - a.pad;
                 for (int tap = 0; tap < KK; ++tap) {
                     const int kh = tap / a.KW, kw = tap - kh * a.KW;
                     const bool inb = (ihb + kh) >= 0 && (ihb + kh) < a.H && (iwb + kw) >= 0 && (iwb + kw) < a.W;
@@ -163,7 +182,8 @@ __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW
             const float fn = (float)(n_inb * a.IC);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int oc = oc_base + (r & 3) + 8 * (r >> 2);
+                const int dr = (r & 3) + 8 * (r >> 2);
+                const int oc = oc_base + dr;
                 float v = (float)acc[t][r];
                 v = fmaf(-zw[r], (float)sxs[t], v);
                 if (need_sw) {
@@ -178,48 +198,66 @@ __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW
                     v = fmaf(fn * zxp, zw[r], v);
                 }
                 const float res = fmaf(al[r], v, bi[r]);
-                if (valid && oc < a.OC) out_n[(int64_t)oc * OHW + q] = res;
+                if (valid[t] && oc < a.OC) (out_w + (int64_t)dr * OHW)[voff[t]] = res;
             }
         }
     }
 }
 
-// WM x WN waves over (oc strips, pixel column tiles); NIW column tiles per wave; KKT = taps known
-// at compile time (1, 9 = 3x3) or 0 for a runtime tap loop; X8 = 8-bit activations.
-template <int WM, int WN, int NIW, int KKT, bool X8>
+// tile decode shared by both kernels.  XCD-aware block map: blocks b and b+8 share an XCD (and its
+// L2); the oc-tiles of one pixel tile get ids that differ by multiples of 8 so they read the same
+// activations from one L2.
+__device__ __forceinline__ bool decode_tile(const MfmaArgs &a, int &pt, int &ot, TileGeom &g, int &th)
+{
+    const int bid = blockIdx.x;
+    const int grp_sz = 8 * a.n_oc_tiles;
+    const int grp = bid / grp_sz, rem = bid - grp * grp_sz;
+    pt = grp * 8 + (rem & 7);
+    ot = rem >> 3;
+    if (pt >= a.n_pix_tiles) return false;
+    const int ng = pt / a.tiles_h;
+    g.n0 = ng * a.GI;
+    g.oh0 = (pt - ng * a.tiles_h) * a.TH;
+    th = min(a.TH, a.OH - g.oh0);
+    g.OHWt = th * a.OW;
+    g.NT = min(a.GI, a.N - g.n0) * g.OHWt;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Main kernel.  WM x WN waves over (oc strips, pixel column tiles); NIW column tiles per wave;
+// KKT = taps known at compile time (1, 9 = 3x3) or 0 for a runtime tap loop; X8 = 8-bit
+// activations; NS = 32-channel chunks per stage: the 256 threads split into NS groups that each
+// fetch one chunk of the stage, so one HBM round trip feeds NS*KK MFMA steps per column tile.
+// ---------------------------------------------------------------------------------------------
+template <int WM, int WN, int NIW, int KKT, bool X8, int NS>
 __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint4 *Xs = reinterpret_cast<uint4 *>(smem);
 
     constexpr int MT = 32 * WM;
+    constexpr int TPS = MF_THREADS / NS;   // staging threads per chunk
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
     const int col = lane & 31, h = lane >> 5;
+    const int sub = __builtin_amdgcn_readfirstlane(tid / TPS);   // which chunk of the stage this wave fetches
 
-    // XCD-aware block map: blocks b and b+8 share an XCD (and its L2); the oc-tiles of one pixel
-    // tile get ids that differ by multiples of 8 so they read the same activations from one L2.
-    const int bid = blockIdx.x;
-    const int grp_sz = 8 * a.n_oc_tiles;
-    const int grp = bid / grp_sz, rem = bid - grp * grp_sz;
-    const int pt = grp * 8 + (rem & 7);
-    const int ot = rem >> 3;
-    if (pt >= a.n_pix_tiles) return;
-
-    const int n = pt / a.tiles_h;
-    const int oh0 = (pt - n * a.tiles_h) * a.TH;
-    const int th = min(a.TH, a.OH - oh0);
-    const int NT = th * a.OW;
-    const int ih0 = oh0 * a.stride - a.pad;
-    const int GSZ = a.IHT * a.IWP;
+    int pt, ot, th;
+    TileGeom g;
+    if (!decode_tile(a, pt, ot, g, th)) return;
+    const int NT = g.NT;
+    const int ih0 = g.oh0 * a.stride - a.pad;
+    const int ISZ = a.IHT * a.IWP;          // halo pixels of one image
+    const int GSZ = a.GI * ISZ;             // halo pixels of one 16-channel group
     const int KK = (KKT > 0) ? KKT : a.KH * a.KW;
-    const int trash = 2 * GSZ + lane;
-    int *sxp = reinterpret_cast<int *>(Xs + 2 * GSZ + MF_TRASH);  // [GSZ] per-input-pixel sums (zw' != 0 only)
+    const int trash = 2 * NS * GSZ + lane;
+    int *sxp = reinterpret_cast<int *>(Xs + 2 * NS * GSZ + MF_TRASH);  // [GSZ] per-input-pixel sums (zw' != 0 only)
 
     // ---- zero the LDS halo image once: borders / padded channels are never written again ----
-    for (int i = tid; i < 2 * GSZ; i += MF_THREADS) Xs[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < 2 * NS * GSZ; i += MF_THREADS) Xs[i] = make_uint4(0, 0, 0, 0);
     for (int i = tid; i < GSZ; i += MF_THREADS) sxp[i] = 0;
 
     // ---- per-lane pixel bases of the wave's column tiles (uint4 index into Xs) ---------------
@@ -228,26 +266,31 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs
 #pragma unroll
     for (int t = 0; t < NIW; ++t) {
         const int q = (wn + t * WN) * 32 + col;
-        const int r = q / a.OW, c = q - r * a.OW;
-        pixidx[t] = h * GSZ + ((q < NT) ? (r * RS) * a.IWP + c * CS : 0);
+        const int gi = (a.GI > 1) ? q / g.OHWt : 0;
+        const int rq = q - gi * g.OHWt;
+        const int r = rq / a.OW, c = rq - r * a.OW;
+        pixidx[t] = h * GSZ + ((q < NT) ? gi * ISZ + (r * RS) * a.IWP + c * CS : 0);
     }
 
-    // ---- staging: thread <-> (halo row l, column quad iq); its two units are the two 16-channel
-    // groups of the chunk, so the channel of every load is wave-uniform (scalar base + ONE per-thread
-    // 32-bit offset) and nothing needs a per-lane clamp. --------------------------------------
+    // ---- staging: thread <-> (image gi, halo row l, column quad iq) of chunk `sub`; its two units are
+    // the two 16-channel groups of that chunk, so the channel of every load is wave-uniform (scalar
+    // base + ONE per-thread 32-bit offset) and nothing needs a per-lane clamp. ------------------
     const int NQ = (a.W + 3) >> 2;
     const int HW = a.H * a.W;
-    const int64_t img_off = (int64_t)n * a.IC * HW;                       // elements
-    int u_off;                 // element offset in a channel plane of (row ih, column iw0)
+    const int64_t img_off = (int64_t)g.n0 * a.IC * HW;                    // elements
+    int u_off;                 // element offset from (image n0, channel 0) of (image gi, row ih, column iw0)
     int u_sh = 0;              // the row's last quad is read 4 bytes back from the row end and shifted
-    int u_lds[4];              // uint4 index of pixel j in group 0 (+GSZ for group 1), or a trash slot
+    int u_lds[4];              // uint4 index of pixel j in group 0 of the stage, or -1
     {
-        const int l = tid / NQ, iq = tid - l * NQ;
+        const int lt = tid - sub * TPS;
+        const int gi = lt / (a.IHT * NQ);
+        const int rr = lt - gi * (a.IHT * NQ);
+        const int l = rr / NQ, iq = rr - l * NQ;
         const int ih = ih0 + l * a.ROWMUL;
-        const bool ok = l < a.IHT && ih >= 0 && ih < a.H;
+        const bool ok = gi < a.GI && g.n0 + gi < a.N && ih >= 0 && ih < a.H;
         int iw0 = 4 * iq;
         if (iw0 + 4 > a.W) { u_sh = 8 * (iw0 + 4 - a.W); iw0 = a.W - 4; }  // never read past the row (W >= 4)
-        u_off = ok ? ih * a.W + iw0 : 0;
+        u_off = ok ? gi * a.IC * HW + ih * a.W + iw0 : 0;
         if (!ok) u_sh = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -255,7 +298,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs
             const int cl = iw + a.pad;
             const int clc = cl / a.COLMUL;
             const bool pok = ok && iw < a.W && (clc * a.COLMUL == cl) && clc < a.IWP;
-            u_lds[j] = pok ? l * a.IWP + clc : -1;
+            u_lds[j] = pok ? (gi * a.IHT + l) * a.IWP + clc : -1;
         }
     }
     const uint8_t *xi = a.x + (X8 ? img_off : 0);   // 8-bit: image base (uniform); sub-8-bit: stream base
@@ -283,7 +326,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs
     // Activation fetch.  No value is ever masked here: rows outside the image belong to threads
     // whose LDS writes go to the trash slots, and channels >= IC meet all-zero weights in Wt (prep).
     uint32_t d[MF_UNITS][16];
-    auto issue_x = [&](int c) __attribute__((always_inline)) {
+    auto issue_x = [&](int s) __attribute__((always_inline)) {
+        const int c = s * NS + sub;
 #pragma unroll
         for (int u = 0; u < MF_UNITS; ++u) {
 #pragma unroll
@@ -312,7 +356,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs
             }
         }
     };
-    auto stage_x = [&](int c) __attribute__((always_inline)) {
+    auto stage_x = [&](int s) __attribute__((always_inline)) {
+        const int c = s * NS + sub;
 #pragma unroll
         for (int u = 0; u < MF_UNITS; ++u) {
             if constexpr (X8) {
@@ -326,7 +371,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs
                              o[0][m], o[1][m], o[2][m], o[3][m]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int idx = u_lds[j] >= 0 ? u_lds[j] + u * GSZ : trash;
+                const int idx = u_lds[j] >= 0 ? u_lds[j] + (sub * 2 + u) * GSZ : trash;
                 Xs[idx] = make_uint4(o[j][0], o[j][1], o[j][2], o[j][3]);
             }
             if (need_sx) {
@@ -345,48 +390,56 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs
             }
         }
     };
-    auto mma_tap = [&](const v4i af, int tapoff) __attribute__((always_inline)) {
+    auto mma_tap = [&](const v4i af, int off) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < NIW; ++t) {
-            const v4i b = *reinterpret_cast<const v4i *>(&Xs[pixidx[t] + tapoff]);
+            const v4i b = *reinterpret_cast<const v4i *>(&Xs[pixidx[t] + off]);
             acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, b, acc[t], 0, 0, 0);
         }
     };
-    // one 32-channel chunk: request A(c) -> X(c) regs into LDS -> barrier -> request X(c+1) -> MFMA
-    auto chunk = [&](int c, auto prefetch) __attribute__((always_inline)) {
-        const int8_t *a_c = a_base + (int64_t)(2 * c) * grp_stride;
-        v4i afr[(KKT > 0) ? KKT : 1];
-        if constexpr (KKT > 0) {
+    // one stage of NS chunks: request A(s) -> X(s) regs into LDS -> barrier -> request X(s+1) -> MFMA
+    auto stage = [&](int s, auto prefetch) __attribute__((always_inline)) {
+        const int8_t *a_s = a_base + (int64_t)(2 * NS * s) * grp_stride;
+        v4i afr[NS][(KKT > 0) ? KKT : 1];
 #pragma unroll
-            for (int tap = 0; tap < KKT; ++tap) afr[tap] = *reinterpret_cast<const v4i *>(a_c + tap * tap_stride + a_voff);
-        } else {
-            afr[0] = *reinterpret_cast<const v4i *>(a_c + a_voff);
+        for (int k = 0; k < NS; ++k) {
+            if constexpr (KKT > 0) {
+#pragma unroll
+                for (int tap = 0; tap < KKT; ++tap)
+                    afr[k][tap] = *reinterpret_cast<const v4i *>(a_s + 2 * k * grp_stride + tap * tap_stride + a_voff);
+            } else {
+                afr[k][0] = *reinterpret_cast<const v4i *>(a_s + 2 * k * grp_stride + a_voff);
+            }
         }
-        stage_x(c);
+        stage_x(s);
         __syncthreads();
-        if constexpr (decltype(prefetch)::value) issue_x(c + 1);
-        if constexpr (KKT > 0) {
+        if constexpr (decltype(prefetch)::value) issue_x(s + 1);
 #pragma unroll
-            for (int tap = 0; tap < KKT; ++tap) {
-                constexpr int KW_T = (KKT == 9) ? 3 : 1;
-                mma_tap(afr[tap], (tap / KW_T) * a.IWP + (tap % KW_T));
-            }
-        } else {
-            v4i af = afr[0];
-            for (int tap = 0; tap < KK; ++tap) {
-                const int nxt = tap + 1 < KK ? tap + 1 : tap;
-                const v4i af_next = *reinterpret_cast<const v4i *>(a_c + nxt * tap_stride + a_voff);
-                const int kh = tap / a.KW;
-                mma_tap(af, kh * a.IWP + (tap - kh * a.KW));
-                af = af_next;
+        for (int k = 0; k < NS; ++k) {
+            if constexpr (KKT > 0) {
+#pragma unroll
+                for (int tap = 0; tap < KKT; ++tap) {
+                    constexpr int KW_T = (KKT == 9) ? 3 : 1;
+                    mma_tap(afr[k][tap], 2 * k * GSZ + (tap / KW_T) * a.IWP + (tap % KW_T));
+                }
+            } else {
+                v4i af = afr[k][0];
+                for (int tap = 0; tap < KK; ++tap) {
+                    const int nxt = tap + 1 < KK ? tap + 1 : tap;
+                    const v4i af_next = *reinterpret_cast<const v4i *>(a_s + 2 * k * grp_stride + nxt * tap_stride + a_voff);
+                    const int kh = tap / a.KW;
+                    mma_tap(af, 2 * k * GSZ + kh * a.IWP + (tap - kh * a.KW));
+                    af = af_next;
+                }
             }
         }
-        __syncthreads();  // everyone is done reading before the next chunk overwrites the image
+        __syncthreads();  // everyone is done reading before the next stage overwrites the image
     };
 
+    const int n_stages = a.NCH / NS;   // NCH is padded to a multiple of NS by the host (zero weights)
     issue_x(0);
-    for (int c = 0; c < a.NCH - 1; ++c) chunk(c, std::true_type{});
-    chunk(a.NCH - 1, std::false_type{});
+    for (int s = 0; s < n_stages - 1; ++s) stage(s, std::true_type{});
+    stage(n_stages - 1, std::false_type{});
 
     // ---- epilogue -----------------------------------------------------------------------------
     int sxs[NIW];
@@ -401,7 +454,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs
             }
         }
     }
-    mfma_epilogue<WM, WN, NIW>(a, acc, sxs, need_sx, n, ot, oh0, NT, wm, wn, col, h, KK);
+    mfma_epilogue<WM, WN, NIW>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -425,17 +478,10 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_smallic_kernel(const 
     const int wm = wave % WM, wn = wave / WM;
     const int col = lane & 31, h = lane >> 5;
 
-    const int bid = blockIdx.x;
-    const int grp_sz = 8 * a.n_oc_tiles;
-    const int grp = bid / grp_sz, rem = bid - grp * grp_sz;
-    const int pt = grp * 8 + (rem & 7);
-    const int ot = rem >> 3;
-    if (pt >= a.n_pix_tiles) return;
-
-    const int n = pt / a.tiles_h;
-    const int oh0 = (pt - n * a.tiles_h) * a.TH;
-    const int th = min(a.TH, a.OH - oh0);
-    const int NT = th * a.OW;
+    int pt, ot, th;
+    TileGeom g;
+    if (!decode_tile(a, pt, ot, g, th)) return;
+    const int n = g.n0, oh0 = g.oh0, NT = g.NT;
     const int ih0 = oh0 * a.stride - a.pad;
     const int GSZ = a.IHT * a.IWP;       // pixels (dwords) in the halo image
     const int KK = a.KH * a.KW;
@@ -533,27 +579,33 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_smallic_kernel(const 
             }
         }
     }
-    mfma_epilogue<WM, WN, NIW>(a, acc, sxs, need_sx, n, ot, oh0, NT, wm, wn, col, h, KK);
+    mfma_epilogue<WM, WN, NIW>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK);
 }
 
 // launchers, one translation unit per wave layout (qe_conv_mfma_i*.hip)
-void launch_mfma_cfg0(const MfmaArgs &a, int niw, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
-void launch_mfma_cfg1(const MfmaArgs &a, int niw, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
-void launch_mfma_cfg2(const MfmaArgs &a, int niw, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
+void launch_mfma_cfg0(const MfmaArgs &a, int niw, int ns, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
+void launch_mfma_cfg1(const MfmaArgs &a, int niw, int ns, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
+void launch_mfma_cfg2(const MfmaArgs &a, int niw, int ns, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_smallic(const MfmaArgs &a, int cfg, unsigned blocks, size_t lds, hipStream_t s);
 
-#define QE_MFMA_LAUNCH(WM, WN, NIW)                                                                       \
-    do {                                                                                                  \
-        if (KK == 1) {                                                                                    \
-            if (x8) hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, NIW, 1, true>), dim3(blocks), dim3(MF_THREADS), lds, s, a);  \
-            else    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, NIW, 1, false>), dim3(blocks), dim3(MF_THREADS), lds, s, a); \
-        } else if (KK == 9 && a.KW == 3) {                                                                \
-            if (x8) hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, NIW, 9, true>), dim3(blocks), dim3(MF_THREADS), lds, s, a);  \
-            else    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, NIW, 9, false>), dim3(blocks), dim3(MF_THREADS), lds, s, a); \
-        } else {                                                                                          \
-            if (x8) hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, NIW, 0, true>), dim3(blocks), dim3(MF_THREADS), lds, s, a);  \
-            else    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, NIW, 0, false>), dim3(blocks), dim3(MF_THREADS), lds, s, a); \
-        }                                                                                                 \
+#define QE_MFMA_K(WM, WN, NIW, KKT, X8, NS) \
+    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, NIW, KKT, X8, NS>), dim3(blocks), dim3(MF_THREADS), lds, s, a)
+
+// 1x1 convolutions get the multi-chunk stages (ns = 1, 2, 4); sub-8-bit activations only ns = 1
+#define QE_MFMA_LAUNCH(WM, WN, NIW)                                                   \
+    do {                                                                              \
+        if (KK == 1) {                                                                \
+            if (!x8)           QE_MFMA_K(WM, WN, NIW, 1, false, 1);                   \
+            else if (ns == 4)  QE_MFMA_K(WM, WN, NIW, 1, true, 4);                    \
+            else if (ns == 2)  QE_MFMA_K(WM, WN, NIW, 1, true, 2);                    \
+            else               QE_MFMA_K(WM, WN, NIW, 1, true, 1);                    \
+        } else if (KK == 9 && a.KW == 3) {                                            \
+            if (x8) QE_MFMA_K(WM, WN, NIW, 9, true, 1);                               \
+            else    QE_MFMA_K(WM, WN, NIW, 9, false, 1);                              \
+        } else {                                                                      \
+            if (x8) QE_MFMA_K(WM, WN, NIW, 0, true, 1);                               \
+            else    QE_MFMA_K(WM, WN, NIW, 0, false, 1);                              \
+        }                                                                             \
     } while (0)
 
 }  // namespace qe

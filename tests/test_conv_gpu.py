@@ -149,6 +149,9 @@ SWEEP_SHAPES = [
     (2, 33, 8, 8, 31, 5, 1, 2),
     (1, 16, 4, 4, 8, 3, 1, 0),
     (5, 8, 1, 1, 12, 1, 1, 0),
+    (5, 64, 7, 7, 32, 3, 1, 1),     # several whole images per tile, last group partial
+    (3, 96, 6, 6, 130, 1, 1, 0),
+    (2, 160, 14, 14, 200, 1, 1, 0),  # multi-chunk stages with a padded last stage
 ]
 
 
