@@ -20,7 +20,7 @@ EXT_DIR = os.path.join(_HERE, "_ext")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 HIP_SOURCES = ["qe_api.hip", "qe_tpack.hip", "qe_conv_generic.hip", "qe_conv_mfma.hip",
-               "qe_conv_mfma_i0.hip", "qe_conv_mfma_i1.hip", "qe_conv_mfma_i2.hip", "qe_conv_mfma_i3.hip"]
+               "qe_conv_mfma_i0.hip", "qe_conv_mfma_i1.hip", "qe_conv_mfma_i2.hip", "qe_conv_mfma_i3.hip", "qe_conv_mfma_i4.hip"]
 HIP_HEADERS = ["qe_common.h", "qe_conv_mfma_kernel.hpp", os.path.join(INCLUDE, "quant_engine.h")]
 ARCH = "gfx950"
 
@@ -41,18 +41,21 @@ def module_path():
     return os.path.join(EXT_DIR, "quant_engine" + suffix)
 
 
-def build_hip(force=False, verbose=False):
+def build_hip(force=False, verbose=False, stamp=False):
     """Each .hip translation unit -> object (in parallel: the MFMA instantiation units dominate),
-    then one link into libqe_hip.so."""
+    then one link into libqe_hip.so.  stamp=True builds the diagnostic variant libqe_hip_stamp.so
+    (-DQE_STAMP: in-kernel s_memtime phase stamps; never the library the product loads)."""
     from concurrent.futures import ThreadPoolExecutor
 
     os.makedirs(EXT_DIR, exist_ok=True)
-    obj_dir = os.path.join(EXT_DIR, "obj")
+    obj_dir = os.path.join(EXT_DIR, "obj_stamp" if stamp else "obj")
     os.makedirs(obj_dir, exist_ok=True)
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     common = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
               "-I", INCLUDE]
+    if stamp:
+        common.append("-DQE_STAMP=1")
     jobs, objs = [], []
     for src in HIP_SOURCES:
         sp = os.path.join(CSRC, src)
@@ -69,7 +72,7 @@ def build_hip(force=False, verbose=False):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) - 1))) as ex:
             list(ex.map(run, jobs))
-    out = lib_path()
+    out = os.path.join(EXT_DIR, "libqe_hip_stamp.so") if stamp else lib_path()
     if jobs or not os.path.exists(out):
         run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs)
     return out
@@ -108,5 +111,8 @@ def build_all(force=False, verbose=False):
 
 if __name__ == "__main__":
     force = "--force" in sys.argv
+    if "--stamp" in sys.argv:
+        print("built", build_hip(force=force, verbose=True, stamp=True))
+        sys.exit(0)
     for p in build_all(force=force, verbose=True):
         print("built", p)

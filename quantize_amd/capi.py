@@ -39,7 +39,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    path = loader.lib_path()
+    path = os.environ.get("QE_LIB") or loader.lib_path()   # QE_LIB: diagnostic builds only (tools/)
     if not os.path.exists(path):
         raise ImportError("libqe_hip.so not built: run `python -m quantize_amd.build`. No fallback exists.")
     L = ctypes.CDLL(path)

@@ -11,7 +11,7 @@ int launch_conv_generic(bool packed_in, const void *x, const qe_qparam *xq, cons
 
 // qe_conv_mfma.hip
 bool mfma_conv_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w);
-size_t mfma_conv_workspace_bytes(const qe_conv_shape *sh, int x_bits);
+size_t mfma_conv_workspace_bytes(const qe_conv_shape *sh, int x_bits, int w_bits);
 int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh,
                      float *out, void *workspace, size_t workspace_bytes, hipStream_t s);
 
@@ -55,9 +55,8 @@ extern "C" const char *qe_target_arch(void) { return "gfx950"; }
 
 extern "C" size_t qe_quantconv2d_workspace_bytes(const qe_conv_shape *shape, int x_bits, int w_bits)
 {
-    (void)w_bits;
     if (qe::check_shape(shape) != QE_OK) return 0;
-    return qe::mfma_conv_workspace_bytes(shape, x_bits);
+    return qe::mfma_conv_workspace_bytes(shape, x_bits, w_bits);
 }
 
 extern "C" int qe_quantconv2d_path(const qe_conv_shape *shape, const qe_qparam *x, const qe_qparam *w)

@@ -175,6 +175,7 @@ struct MfmaPlan {
     int TH = 0, ni = 0, niw = 0, IHT = 0, IWP = 0, ROWMUL = 1, COLMUL = 1;
     bool smallic = false;
     int GI = 1, NS = 1;
+    bool flat = false, wraw = false;
     size_t lds = 0;
     size_t wt_bytes = 0, ep_off = 0, ws_off = 0, total = 0;
 };
@@ -185,7 +186,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static const int kNiw[3][3] = {{7, 4, 2}, {4, 2, 1}, {2, 1, 0}};
 static const int kWN[3] = {1, 2, 4};
 
-static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits)
+static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits, int w_bits)
 {
     MfmaPlan p;
     p.OH = (sh->H + 2 * sh->padding - sh->KH) / sh->stride + 1;
@@ -204,8 +205,26 @@ static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits)
     if (p.KK > 64 || p.OW > 32 * max_tiles) return p;
     p.OCP = (sh->OC + p.MT - 1) / p.MT * p.MT;
     const int NQ = (sh->W + 3) / 4;
+    const int P = sh->H * sh->W;
+    p.flat = p.KK == 1 && sh->stride == 1 && sh->padding == 0 && x_bits == 8 && (P % 4) == 0 && P >= 64 && sh->IC >= 16;
+    if (p.flat) {
+        // 1x1 / stride 1 / no padding: GEMM over the flat pixel index (conv_mfma_flat_kernel)
+        const int ntp = 32 * max_tiles;
+        const int rstr = 32 * (max_tiles | 1);
+        const int nch = (sh->IC + 31) / 32;
+        p.NS = 1;
+        for (int cand = 4; cand > 1; cand >>= 1)
+            if (cand <= nch && (size_t)(32 * cand) * rstr + (size_t)ntp * 4 <= (size_t)MF_MAX_LDS) { p.NS = cand; break; }
+        p.lds = std::max((size_t)(32 * p.NS) * rstr, (size_t)4 * 32 * 36 * 4) + (size_t)ntp * 4;
+        p.TH = 1; p.ni = max_tiles; p.niw = kNiw[p.cfg][0];
+        p.NCH = nch; p.NG = 2 * nch;
+        p.wraw = (w_bits == 8) && (sh->IC % 16) == 0;
+        p.wt_bytes = p.wraw ? 0 : (size_t)p.NG * p.OCP * 16;
+        p.IHT = (P + ntp - 1) / ntp;   // pixel tiles per image
+    } else
     p.smallic = sh->IC <= 4 && sh->KW <= 8 && sh->KH <= 8 && x_bits == 8;
-    if (p.smallic) {
+    if (p.flat) {
+    } else if (p.smallic) {
         // stem layout: K = (kh) x [kw 0..7][ic 0..3]; the whole (tiny) channel depth is one stage
         p.NCH = 1;
         p.NG = 2;
@@ -258,6 +277,7 @@ static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits)
             if (kNiw[p.cfg][i] > 0 && kNiw[p.cfg][i] * kWN[p.cfg] >= p.ni) p.niw = kNiw[p.cfg][i];
         p.wt_bytes = (size_t)p.KK * p.NG * p.OCP * 16;
     }
+    if (p.flat && p.wraw) { p.total = 0; p.ok = true; return p; }
     p.ep_off = align_up(p.wt_bytes, 256);
     p.ws_off = align_up(p.ep_off + (size_t)3 * p.OCP * sizeof(float), 256);
     p.total = align_up(p.ws_off + (size_t)p.OCP * (p.KK + 1) * sizeof(int), 256);
@@ -265,26 +285,30 @@ static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits)
     return p;
 }
 
+// diagnostic (-DQE_STAMP) builds: where the kernels drop their per-wave phase sums
+static unsigned long long *g_mfma_dbg = nullptr;
+
 bool mfma_conv_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w)
 {
-    (void)w;
     if (x->n_param != 1) return false;  // per-channel activation scale cannot leave the K sum
-    return make_plan(sh, x->n_bits).ok;
+    return make_plan(sh, x->n_bits, w->n_bits).ok;
 }
 
-size_t mfma_conv_workspace_bytes(const qe_conv_shape *sh, int x_bits)
+size_t mfma_conv_workspace_bytes(const qe_conv_shape *sh, int x_bits, int w_bits)
 {
-    const MfmaPlan p = make_plan(sh, x_bits);
+    const MfmaPlan p = make_plan(sh, x_bits, w_bits);
     return p.ok ? p.total : 0;
 }
 
 int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh,
                      float *out, void *workspace, size_t workspace_bytes, hipStream_t s)
 {
-    const MfmaPlan p = make_plan(sh, x->n_bits);
+    const MfmaPlan p = make_plan(sh, x->n_bits, w->n_bits);
     if (!p.ok) return QE_ERR_UNSUPPORTED;
-    if (workspace == nullptr || workspace_bytes < p.total) return QE_ERR_WORKSPACE;
-    if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return QE_ERR_ARG;
+    if (p.total > 0) {
+        if (workspace == nullptr || workspace_bytes < p.total) return QE_ERR_WORKSPACE;
+        if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return QE_ERR_ARG;
+    }
     uint8_t *wsp = static_cast<uint8_t *>(workspace);
 
     PrepArgs pa;
@@ -294,7 +318,9 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     pa.wt = reinterpret_cast<int8_t *>(wsp);
     pa.ep = reinterpret_cast<float *>(wsp + p.ep_off);
     pa.ws = reinterpret_cast<int *>(wsp + p.ws_off);
-    if (p.smallic)
+    if (p.flat && p.wraw) {
+        // nothing to prepare: the kernel reads the packed tensor and builds its constants itself
+    } else if (p.smallic)
         hipLaunchKernelGGL(conv_mfma_prep_smallic_kernel, dim3(p.OCP), dim3(64), 0, s, pa, (int)sh->KH, (int)sh->KW);
     else
         hipLaunchKernelGGL(conv_mfma_prep_kernel, dim3(p.OCP), dim3(256), 0, s, pa);
@@ -310,7 +336,15 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     a.OCP = p.OCP; a.NG = p.NG; a.NCH = p.NCH;
     a.TH = p.TH; a.tiles_h = (p.OH + p.TH - 1) / p.TH;
     a.GI = p.GI;
+    a.dbg = g_mfma_dbg;
+    a.w_raw = w->data; a.w_scale = w->scale; a.w_zero = w->zero; a.x_scale = x->scale; a.bias = bias;
+    a.w_bits = w->n_bits; a.w_sign = w->sign; a.w_per_tensor = (w->n_param == 1);
+
     a.n_pix_tiles = ((sh->N + p.GI - 1) / p.GI) * a.tiles_h;
+    if (p.flat) {
+        a.tiles_h = p.IHT;                       // pixel tiles per image
+        a.n_pix_tiles = sh->N * a.tiles_h;
+    }
     a.n_oc_tiles = p.OCP / p.MT;
     a.IHT = p.IHT; a.IWP = p.IWP; a.ROWMUL = p.ROWMUL; a.COLMUL = p.COLMUL; a.ni = p.ni;
 
@@ -318,6 +352,11 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     const int64_t blocks = groups * 8 * a.n_oc_tiles;
     if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
     const bool x8 = x->n_bits == 8;
+    if (p.flat) {
+        launch_mfma_flat(a, p.cfg, p.NS, p.wraw, (unsigned)blocks, p.lds, s);
+        QE_LAUNCH_CHECK();
+        return QE_OK;
+    }
     if (p.smallic) {
         launch_mfma_smallic(a, p.cfg, (unsigned)blocks, p.lds, s);
         QE_LAUNCH_CHECK();
@@ -333,3 +372,7 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
 }
 
 }  // namespace qe
+
+// Not part of the public ABI (absent from include/quant_engine.h): set the stamp buffer of a
+// -DQE_STAMP diagnostic build.
+extern "C" void qe_debug_set_stamp_buffer(unsigned long long *p) { qe::g_mfma_dbg = p; }

@@ -1,0 +1,31 @@
+// qe_conv_mfma_i4.hip -- instantiations of the flat 1x1 MFMA kernel.
+#include "qe_conv_mfma_kernel.hpp"
+
+namespace qe {
+
+#define QE_FLAT(WM, WN, NIW, NS, WRAW) \
+    hipLaunchKernelGGL((conv_mfma_flat_kernel<WM, WN, NIW, NS, WRAW>), dim3(blocks), dim3(MF_THREADS), lds, s, a)
+
+#define QE_FLAT_NS(WM, WN, NIW)                                     \
+    do {                                                            \
+        if (wraw) {                                                 \
+            if (ns == 4) QE_FLAT(WM, WN, NIW, 4, true);             \
+            else if (ns == 2) QE_FLAT(WM, WN, NIW, 2, true);        \
+            else QE_FLAT(WM, WN, NIW, 1, true);                     \
+        } else {                                                    \
+            if (ns == 4) QE_FLAT(WM, WN, NIW, 4, false);            \
+            else if (ns == 2) QE_FLAT(WM, WN, NIW, 2, false);       \
+            else QE_FLAT(WM, WN, NIW, 1, false);                    \
+        }                                                           \
+    } while (0)
+
+void launch_mfma_flat(const MfmaArgs &a, int cfg, int ns, bool wraw, unsigned blocks, size_t lds, hipStream_t s)
+{
+    switch (cfg) {
+        case 0: QE_FLAT_NS(4, 1, 7); break;
+        case 1: QE_FLAT_NS(2, 2, 4); break;
+        default: QE_FLAT_NS(1, 4, 2); break;
+    }
+}
+
+}  // namespace qe

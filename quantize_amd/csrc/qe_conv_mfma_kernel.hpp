@@ -31,6 +31,11 @@ struct MfmaArgs {
     int TH, tiles_h, n_pix_tiles, n_oc_tiles;
     int IHT, IWP, ROWMUL, COLMUL, ni;
     int GI;                    // whole images per pixel tile (> 1 only for small feature maps, TH == OH)
+    unsigned long long *dbg;   // diagnostic builds (-DQE_STAMP) only: per-wave phase cycle sums
+    // raw operands, used by the flat 1x1 kernel (it builds its epilogue constants itself)
+    const uint8_t *w_raw;      // packed OIHW weights as the caller passed them
+    const float *w_scale, *w_zero, *x_scale, *bias;
+    int w_bits, w_sign, w_per_tensor;
 };
 
 // stored code u -> MFMA operand a = q - d = u - c, c = off (signed) | 128 (unsigned 8-bit) | 0
@@ -75,6 +80,21 @@ __device__ __forceinline__ uint32_t fetch_quad(const uint8_t *__restrict__ xi, i
         return r;
     }
 }
+
+#ifdef QE_STAMP
+// In-kernel stamps (guide section 7): one asm statement, fenced, lgkmcnt(0) inside.  Diagnostic build only.
+__device__ __forceinline__ unsigned long long qe_stamp()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define QE_ST(i) do { const unsigned long long _t = qe_stamp(); st[i] += _t - tprev; tprev = _t; } while (0)
+#else
+#define QE_ST(i) do { } while (0)
+#endif
 
 // 4x4 byte transpose: in d0..d3 (one channel each, 4 pixels), out o0..o3 (one pixel each, 4 channels)
 __device__ __forceinline__ void transpose4x4(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3,
@@ -323,6 +343,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs
     if (tid < MT) zw_local = (a.ep[a.OCP + ot * MT + tid] != 0.0f) ? 1 : 0;
     const bool need_sx = __syncthreads_or(zw_local) != 0;  // also orders the LDS zero fill
 
+#ifdef QE_STAMP
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = qe_stamp();
+    const unsigned long long tstart = tprev;
+#endif
     // Activation fetch.  No value is ever masked here: rows outside the image belong to threads
     // whose LDS writes go to the trash slots, and channels >= IC meet all-zero weights in Wt (prep).
     uint32_t d[MF_UNITS][16];
@@ -411,9 +436,13 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs
                 afr[k][0] = *reinterpret_cast<const v4i *>(a_s + 2 * k * grp_stride + a_voff);
             }
         }
+        QE_ST(0);   // A requests issued
         stage_x(s);
+        QE_ST(1);   // wait X + transpose + LDS writes
         __syncthreads();
+        QE_ST(2);   // barrier 1
         if constexpr (decltype(prefetch)::value) issue_x(s + 1);
+        QE_ST(3);   // X(s+1) issue
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             if constexpr (KKT > 0) {
@@ -433,7 +462,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs
                 }
             }
         }
+        QE_ST(4);   // MFMA phase
         __syncthreads();  // everyone is done reading before the next stage overwrites the image
+        QE_ST(5);   // barrier 2
     };
 
     const int n_stages = a.NCH / NS;   // NCH is padded to a multiple of NS by the host (zero weights)
@@ -454,7 +485,19 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs
             }
         }
     }
+#ifdef QE_STAMP
+    QE_ST(6);       // (prologue of the epilogue)
+#endif
     mfma_epilogue<WM, WN, NIW>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK);
+#ifdef QE_STAMP
+    QE_ST(7);       // epilogue stores issued
+    if (a.dbg != nullptr && lane == 0) {
+        unsigned long long *o = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 10;
+        for (int i = 0; i < 8; ++i) o[i] = st[i];
+        o[8] = tprev - tstart;
+        o[9] = tstart;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -582,11 +625,251 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_smallic_kernel(const 
     mfma_epilogue<WM, WN, NIW>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Flat 1x1 kernel: KH = KW = 1, stride 1, padding 0, 8-bit activations, H*W % 4 == 0.
+// A 1x1 convolution is a plain GEMM per image: out[oc][p] = sum_c W[oc][c] X[c][p] over the FLAT
+// pixel index p of the NCHW planes.  Nothing has to be transposed by hand here:
+//   * activations go global -> VGPR -> LDS in their native [channel][pixel] order as 16-byte pieces
+//     (16 pixels of one channel per lane: 4.5x fewer load instructions than the halo kernel's
+//     dword fetch, no v_perm work);
+//   * MFMA operands want 16 K-contiguous bytes per lane: ds_read_b64_tr_b8 (gfx950's transposed LDS
+//     read, semantics probed in tools/probe_tr_b8.hip: lane i of a 16-lane group receives column i
+//     of an 8-row x 16-byte block whose row r address comes from lanes 2r, 2r+1) delivers exactly
+//     that from the row-major image, two reads per fragment;
+//   * the row stride is 32*(odd) bytes, so the 8 rows of a transposed read hit 8 distinct 32-byte
+//     bank groups: conflict free;
+//   * operand roles are swapped w.r.t. the halo kernel: A = activations (rows = pixels), B = weights
+//     (cols = output channel).  D then has the output channel on the lane and 4 consecutive pixels
+//     in 4 consecutive registers: every store is a 16-byte global_store_dwordx4 (4x fewer store
+//     instructions), and alpha / bias / zero-point terms are ONE value per lane;
+//   * 8-bit weights with IC % 16 == 0 are consumed straight from the packed OIHW tensor (row oc,
+//     16 channels = 16 contiguous bytes, u ^ 0x80 in registers): no prep launch for these layers.
+//     S_w (sum of weights per output channel, needed when zx' != 0) falls out of the same
+//     fragments with v_dot4.
+// Template: WM x WN waves (oc strips x pixel tiles), NIW pixel tiles per wave, NS 32-channel chunks
+// per stage, WRAW = weights read from the packed tensor (else from the prep'd Wt).
+// ---------------------------------------------------------------------------------------------
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+template <int WM, int WN, int NIW, int NS, bool WRAW>
+__global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const MfmaArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    constexpr int MT = 32 * WM;
+    constexpr int NTILES = NIW * WN;
+    constexpr int NTP = 32 * NTILES;            // pixels per tile
+    constexpr int RSTR = 32 * (NTILES | 1);     // LDS row stride: odd multiple of 32 B
+    constexpr int CK = 32 * NS;                 // channels per stage
+    constexpr int SEGS = NTP / 16;              // 16-pixel pieces per channel row
+    constexpr int PPT = (CK * SEGS + MF_THREADS - 1) / MF_THREADS;  // pieces per thread per stage
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int col = lane & 31, h = lane >> 5;
+
+    const int P = a.H * a.W;                    // == OH*OW
+    const int bid = blockIdx.x;
+    const int grp_sz = 8 * a.n_oc_tiles;
+    const int grp = bid / grp_sz, rem = bid - grp * grp_sz;
+    const int pt = grp * 8 + (rem & 7);
+    const int ot = rem >> 3;
+    if (pt >= a.n_pix_tiles) return;
+    const int n = pt / a.tiles_h;               // tiles_h = pixel tiles per image here
+    const int p0 = (pt - n * a.tiles_h) * NTP;
+    const int NT = min(NTP, P - p0);            // valid pixels of this tile (multiple of 4)
+
+    uint8_t *Xs = smem;                                                   // [CK][RSTR]
+    constexpr int XS_BYTES = (CK * RSTR > 4 * 32 * 36 * 4) ? CK * RSTR : 4 * 32 * 36 * 4;  // image, later the epilogue patches
+    int *sxp = reinterpret_cast<int *>(smem + XS_BYTES);                  // [NTP], only when zw' != 0
+
+    // ---- epilogue constants of this lane's output channel -----------------------------------
+    const int oc = ot * MT + wm * 32 + col;
+    const int occ = oc < a.OC ? oc : a.OC - 1;
+    const float sw = a.w_per_tensor ? a.w_scale[0] : a.w_scale[occ];
+    const float zwp = (a.w_per_tensor ? a.w_zero[0] : a.w_zero[occ]) - zero_shift(a.w_bits, a.w_sign);
+    const float alpha = a.x_scale[0] * sw;
+    const float bia = a.bias ? a.bias[occ] : 0.0f;
+    const float zxp = a.x_zero[0] - zero_shift(a.x_bits, a.x_sign);
+    const bool need_sx = __syncthreads_or((oc < a.OC && zwp != 0.0f) ? 1 : 0) != 0;   // workgroup-uniform
+    if (need_sx) {
+        for (int i = tid; i < NTP; i += MF_THREADS) sxp[i] = 0;
+    }
+
+    // ---- staging pieces of this thread (stage invariant) -------------------------------------
+    // piece e = tid + 256*i <-> (channel c = e / SEGS of the stage, 16-pixel segment s = e % SEGS).
+    // The read is clamped to end at the plane's end (P >= 16); a clamped piece is rotated back by
+    // whole dwords (P % 4 == 0), so no read ever leaves the tensor.
+    const int64_t img = (int64_t)n * a.IC * P;
+    const uint8_t *xi = a.x + img;
+    int pc[PPT];          // channel within the stage
+    int poff[PPT];        // clamped pixel offset inside the plane
+    int prot[PPT];        // dwords to rotate (0 = piece was not clamped)
+    int plds[PPT];        // LDS byte offset, or -1 when the piece does not exist
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int e = tid + MF_THREADS * i;
+        const int c = e / SEGS, sg = e - c * SEGS;
+        const int px = p0 + 16 * sg;
+        const bool ok = c < CK && 16 * sg < NT;
+        const int pxc = px < P - 16 ? px : P - 16;
+        pc[i] = c < CK ? c : 0;
+        poff[i] = ok ? pxc : 0;
+        prot[i] = ok ? (px - pxc) >> 2 : 0;
+        plds[i] = ok ? c * RSTR + 16 * sg : -1;
+    }
+
+    // ---- weight fragment addressing -----------------------------------------------------------
+    // WRAW: lane (oc, half h) reads 16 contiguous bytes of row oc of the packed OIHW tensor.
+    // else: prep'd Wt[0][icg][OCP][16].
+    const int NGR = (a.IC + 15) >> 4;           // real 16-channel groups
+    const uint8_t *w_lane = WRAW ? a.w_raw + (int64_t)occ * a.IC : nullptr;
+    const int8_t *wt_base = a.wt + (int64_t)(ot * MT + wm * 32) * 16;
+    const uint32_t wt_voff = (uint32_t)col * 16u;
+
+    v16i acc[NIW];
+#pragma unroll
+    for (int t = 0; t < NIW; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0;
+    }
+    int swacc = 0;        // sum of this lane's weight bytes (its half of every chunk)
+
+    // transposed-read base of this lane: row (i>>1) of an 8-row block, column half (i&1), 16-pixel
+    // group (lane>>4)&1 of the 32-pixel tile, channel half h of the 32-channel chunk
+    const int i16 = lane & 15;
+    const int tr_base = (16 * h + (i16 >> 1)) * RSTR + 16 * ((lane >> 4) & 1) + 8 * (i16 & 1);
+
+    uint4 d[PPT];
+    auto issue_x = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int cg = s * CK + pc[i];
+            const int cgc = cg < a.IC ? cg : a.IC - 1;
+            const uint8_t *src = xi + (uint32_t)(cgc * P + poff[i]);
+            __builtin_memcpy(&d[i], src, 16);     // one (4-byte aligned) global_load_dwordx4
+        }
+    };
+    auto stage_x = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            uint32_t v0 = d[i].x, v1 = d[i].y, v2 = d[i].z, v3 = d[i].w;
+            // rotate a clamped tail piece back: out[j] = in[(j + rot) & 3]; rot is 0 almost everywhere
+            const int rot = prot[i];
+            const uint32_t r0 = rot == 0 ? v0 : (rot == 1 ? v1 : (rot == 2 ? v2 : v3));
+            const uint32_t r1 = rot == 0 ? v1 : (rot == 1 ? v2 : (rot == 2 ? v3 : v0));
+            const uint32_t r2 = rot == 0 ? v2 : (rot == 1 ? v3 : (rot == 2 ? v0 : v1));
+            const uint32_t r3 = rot == 0 ? v3 : (rot == 1 ? v0 : (rot == 2 ? v1 : v2));
+            const uint4 w4 = make_uint4(r0 ^ 0x80808080u, r1 ^ 0x80808080u, r2 ^ 0x80808080u, r3 ^ 0x80808080u);
+            if (plds[i] >= 0) {
+                *reinterpret_cast<uint4 *>(Xs + plds[i]) = w4;
+                if (need_sx && s * CK + pc[i] < a.IC) {
+                    // rare path (asymmetric weights): S_x[p] = sum over real channels of a_x
+                    const int pb = (plds[i] - pc[i] * RSTR);
+                    const uint32_t ww[4] = {w4.x, w4.y, w4.z, w4.w};
+                    for (int j = 0; j < 16; ++j)
+                        atomicAdd(&sxp[pb + j], (int)(int8_t)(ww[j >> 2] >> (8 * (j & 3))));
+                }
+            }
+        }
+    };
+    auto stage = [&](int s, auto prefetch) __attribute__((always_inline)) {
+        // (1) weight fragments of the stage's NS chunks
+        v4i wf[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int icg = 2 * (s * NS + k) + h;                 // 16-channel group of this lane half
+            const int icgc = icg < NGR ? icg : NGR - 1;
+            v4i f;
+            if constexpr (WRAW) {
+                __builtin_memcpy(&f, w_lane + icgc * 16, 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f[j] ^= (int)0x80808080;   // u - 128: signed q, or unsigned q - 128
+            } else {
+                f = *reinterpret_cast<const v4i *>(wt_base + (int64_t)icgc * a.OCP * 16 + wt_voff);
+            }
+            if (icg >= NGR) f = v4i{0, 0, 0, 0};                  // channel padding of the last chunk
+            wf[k] = f;
+        }
+        // (2) activations of this stage: registers -> LDS
+        stage_x(s);
+        __syncthreads();
+        // (3) next stage's activations in flight under the MFMA phase
+        if constexpr (decltype(prefetch)::value) issue_x(s + 1);
+        // (4) MFMA: A = transposed activation fragment (rows = pixels), B = weights (cols = oc)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) swacc = __builtin_amdgcn_sdot4(wf[k][j], 0x01010101, swacc, false);
+#pragma unroll
+            for (int t = 0; t < NIW; ++t) {
+                const uint8_t *src = Xs + tr_base + (k * 32) * RSTR + (wn + t * WN) * 32;
+                const v2i lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
+                    (v2i __attribute__((address_space(3))) *)(src));
+                const v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
+                    (v2i __attribute__((address_space(3))) *)(src + 8 * RSTR));
+                const v4i xf = {lo[0], lo[1], hi[0], hi[1]};
+                acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xf, wf[k], acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    };
+
+    const int n_stages = (a.IC + CK - 1) / CK;
+    issue_x(0);
+    for (int s = 0; s < n_stages - 1; ++s) stage(s, std::true_type{});
+    stage(n_stages - 1, std::false_type{});
+
+    // ---- epilogue: lane = output channel, 4 consecutive registers = 4 consecutive pixels ------
+    const int sw_sum = swacc + __shfl_xor(swacc, 32);   // both channel halves
+    // out = bias + alpha * (S_aw - zw' S_x - zx' S_w + IC zx' zw')   (1x1, no padding: every tap in bounds)
+    const float cst = fmaf((float)a.IC * zxp, zwp, -zxp * (float)sw_sum);
+    // D holds 4 consecutive pixels of ONE output channel per lane; stored as-is every instruction
+    // would touch 32 channel rows x 32 bytes (partial 128-byte lines: measured slower than dword
+    // stores of full lines).  Each wave therefore turns its 32 oc x 32 px tile through a private LDS
+    // patch (row stride 36 floats: conflict-free b128 writes) and reads it back with 8 lanes per
+    // channel row: one global_store_dwordx4 then writes 8 rows x 128 contiguous bytes.
+    float *out_w = a.out + ((int64_t)n * a.OC + ot * MT + wm * 32) * P + p0;   // wave-uniform
+    float *patch = reinterpret_cast<float *>(smem) + wave * (32 * 36);         // staging LDS is free now
+    const int rrow = lane >> 3, rq = lane & 7;                                 // read-back: row within 8, pixel quad
+    const uint32_t voff = (uint32_t)rrow * (uint32_t)P + 4u * (uint32_t)rq;
+#pragma unroll
+    for (int t = 0; t < NIW; ++t) {
+        const int q0 = (wn + t * WN) * 32;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float f = (float)acc[t][4 * gq + j] + cst;
+                if (need_sx) f = fmaf(-zwp, (float)sxp[q0 + 8 * gq + 4 * h + j], f);
+                v[j] = fmaf(alpha, f, bia);
+            }
+            *reinterpret_cast<float4 *>(patch + col * 36 + 8 * gq + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        // same wave wrote and reads: only the LDS counter has to drain
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+        const bool px_ok = q0 + 4 * rq < NT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 8 * i + rrow;
+            const float4 o4 = *reinterpret_cast<const float4 *>(patch + row * 36 + 4 * rq);
+            if (px_ok && ot * MT + wm * 32 + row < a.OC)
+                *reinterpret_cast<float4 *>(out_w + (int64_t)(8 * i) * P + q0 + voff) = o4;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // reads done before the next tile overwrites the patch
+    }
+}
+
 // launchers, one translation unit per wave layout (qe_conv_mfma_i*.hip)
 void launch_mfma_cfg0(const MfmaArgs &a, int niw, int ns, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_cfg1(const MfmaArgs &a, int niw, int ns, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_cfg2(const MfmaArgs &a, int niw, int ns, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_smallic(const MfmaArgs &a, int cfg, unsigned blocks, size_t lds, hipStream_t s);
+void launch_mfma_flat(const MfmaArgs &a, int cfg, int ns, bool wraw, unsigned blocks, size_t lds, hipStream_t s);
 
 #define QE_MFMA_K(WM, WN, NIW, KKT, X8, NS) \
     hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, NIW, KKT, X8, NS>), dim3(blocks), dim3(MF_THREADS), lds, s, a)

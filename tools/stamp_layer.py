@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Per-phase cycle breakdown of conv_mfma_kernel from the -DQE_STAMP diagnostic build.
+usage: QE_LIB=quantize_amd/_ext/libqe_hip_stamp.so python tools/stamp_layer.py 28 3 13 ..."""
+import ctypes, os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import torch
+from quantize_amd import capi, resnet50
+import argparse
+from bench import Layer
+
+class A: pass
+args = A(); args.a_bits = 8; args.w_bits = 8; args.asymmetric = False
+L = capi.lib()
+dev = torch.device("cuda", 0)
+specs = resnet50.conv_layers()
+names = ["A issue", "X wait+transpose+LDSwr", "barrier1", "X(s+1) issue", "MFMA phase", "barrier2", "pre-epilogue", "epilogue", "total"]
+for idx in [int(v) for v in sys.argv[1:]]:
+    layer = Layer(idx, specs[idx], 256, dev, args, 0, capi, resnet50, torch)
+    nblocks_max = 1 << 20
+    buf = torch.zeros(nblocks_max * 4 * 10, dtype=torch.int64, device=dev)
+    L.qe_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    layer.run(st); torch.cuda.synchronize()
+    buf.zero_(); layer.run(st); torch.cuda.synchronize()
+    d = buf.view(-1, 10)
+    d = d[d[:, 8] > 0].double()
+    print("layer %d %s %s: %d waves" % (idx, specs[idx].name, tuple(specs[idx][1:]), d.shape[0]))
+    tot = d[:, 8].mean().item()
+    for i in range(8):
+        m = d[:, i].mean().item()
+        print("   %-26s %9.0f cyc  %5.1f%%" % (names[i], m, 100 * m / tot))
+    print("   %-26s %9.0f cyc; span first->last start %.0f" % ("total per wave", tot, (d[:, 9].max() - d[:, 9].min()).item()))
+    L.qe_debug_set_stamp_buffer(None)
