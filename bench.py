@@ -90,6 +90,15 @@ def cpu_baseline(layers, args, torch):
     import numpy as np
     import oracle
     n_img = args.cpu_images
+    # the cores this process may really use (cgroup quota / affinity), not the host's core count
+    avail = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            avail = max(1, min(avail, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    oracle.set_num_threads(avail)
     threads = oracle.num_threads()
     work = []
     for L in layers:
@@ -151,8 +160,10 @@ def main():
         for L in layers:
             L.run(sp)
 
+    pool = torch.full((last.out.shape[2] * last.out.shape[3],), 1.0 / (last.out.shape[2] * last.out.shape[3]), device=dev)
+
     def tail():
-        feats = last.out.mean(dim=(2, 3))
+        feats = (last.out.view(N * last.spec.OC, -1) @ pool).view(N, last.spec.OC)   # global average pool as a gemv
         logits = feats @ fc_w.t()
         logits = qdist.gather_logits(logits) if world > 1 else logits
         return logits.argmax(dim=1)

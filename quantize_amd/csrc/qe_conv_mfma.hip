@@ -39,6 +39,7 @@
 #include "qe_conv_mfma_kernel.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace qe {
 
@@ -209,14 +210,22 @@ static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits, int w_bits)
     p.flat = p.KK == 1 && sh->stride == 1 && sh->padding == 0 && x_bits == 8 && (P % 4) == 0 && P >= 64 && sh->IC >= 16;
     if (p.flat) {
         // 1x1 / stride 1 / no padding: GEMM over the flat pixel index (conv_mfma_flat_kernel)
-        const int ntp = 32 * max_tiles;
-        const int rstr = 32 * (max_tiles | 1);
+        int tiles = max_tiles;
+        if (p.cfg == 0) {
+            // shallow layers (a single stage) are latency- not MFMA-bound: 128-pixel tiles keep the
+            // accumulators small enough for a third workgroup per CU.  QE_FLAT_NIW overrides (tuning).
+            const char *ov = getenv("QE_FLAT_NIW");
+            if (ov != nullptr && atoi(ov) == 4) tiles = 4;
+            else if (ov == nullptr && sh->IC <= 128) tiles = 4;
+        }
+        const int ntp = 32 * tiles;
+        const int rstr = 32 * (tiles | 1);
         const int nch = (sh->IC + 31) / 32;
         p.NS = 1;
         for (int cand = 4; cand > 1; cand >>= 1)
             if (cand <= nch && (size_t)(32 * cand) * rstr + (size_t)ntp * 4 <= (size_t)MF_MAX_LDS) { p.NS = cand; break; }
         p.lds = std::max((size_t)(32 * p.NS) * rstr, (size_t)4 * 32 * 36 * 4) + (size_t)ntp * 4;
-        p.TH = 1; p.ni = max_tiles; p.niw = kNiw[p.cfg][0];
+        p.TH = 1; p.ni = tiles; p.niw = tiles / kWN[p.cfg];
         p.NCH = nch; p.NG = 2 * nch;
         p.wraw = (w_bits == 8) && (sh->IC % 16) == 0;
         p.wt_bytes = p.wraw ? 0 : (size_t)p.NG * p.OCP * 16;
@@ -341,19 +350,24 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     a.w_bits = w->n_bits; a.w_sign = w->sign; a.w_per_tensor = (w->n_param == 1);
 
     a.n_pix_tiles = ((sh->N + p.GI - 1) / p.GI) * a.tiles_h;
+    a.n_oc_tiles = p.OCP / p.MT;
+    int64_t n_units = a.n_pix_tiles;             // what the XCD-aware block map distributes
     if (p.flat) {
         a.tiles_h = p.IHT;                       // pixel tiles per image
         a.n_pix_tiles = sh->N * a.tiles_h;
+        n_units = a.n_pix_tiles;   // one pixel tile per workgroup: runs of several tiles with cross-tile
+                                   // prefetch were measured and never paid ('what did not work')
+    } else {
+        n_units = a.n_pix_tiles;
     }
-    a.n_oc_tiles = p.OCP / p.MT;
     a.IHT = p.IHT; a.IWP = p.IWP; a.ROWMUL = p.ROWMUL; a.COLMUL = p.COLMUL; a.ni = p.ni;
 
-    const int64_t groups = ((int64_t)a.n_pix_tiles + 7) / 8;
+    const int64_t groups = (n_units + 7) / 8;
     const int64_t blocks = groups * 8 * a.n_oc_tiles;
     if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
     const bool x8 = x->n_bits == 8;
     if (p.flat) {
-        launch_mfma_flat(a, p.cfg, p.NS, p.wraw, (unsigned)blocks, p.lds, s);
+        launch_mfma_flat(a, p.cfg, p.niw, p.NS, p.wraw, (unsigned)blocks, p.lds, s);
         QE_LAUNCH_CHECK();
         return QE_OK;
     }

@@ -19,10 +19,12 @@ namespace qe {
         }                                                           \
     } while (0)
 
-void launch_mfma_flat(const MfmaArgs &a, int cfg, int ns, bool wraw, unsigned blocks, size_t lds, hipStream_t s)
+void launch_mfma_flat(const MfmaArgs &a, int cfg, int niw, int ns, bool wraw, unsigned blocks, size_t lds, hipStream_t s)
 {
     switch (cfg) {
-        case 0: QE_FLAT_NS(4, 1, 7); break;
+        case 0:
+            if (niw == 4) QE_FLAT_NS(4, 1, 4); else QE_FLAT_NS(4, 1, 7);
+            break;
         case 1: QE_FLAT_NS(2, 2, 4); break;
         default: QE_FLAT_NS(1, 4, 2); break;
     }

@@ -694,10 +694,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
     const float alpha = a.x_scale[0] * sw;
     const float bia = a.bias ? a.bias[occ] : 0.0f;
     const float zxp = a.x_zero[0] - zero_shift(a.x_bits, a.x_sign);
-    const bool need_sx = __syncthreads_or((oc < a.OC && zwp != 0.0f) ? 1 : 0) != 0;   // workgroup-uniform
-    if (need_sx) {
-        for (int i = tid; i < NTP; i += MF_THREADS) sxp[i] = 0;
-    }
 
     // ---- staging pieces of this thread (stage invariant) -------------------------------------
     // piece e = tid + 256*i <-> (channel c = e / SEGS of the stage, 16-pixel segment s = e % SEGS).
@@ -753,6 +749,14 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
             __builtin_memcpy(&d[i], src, 16);     // one (4-byte aligned) global_load_dwordx4
         }
     };
+    issue_x(0);   // in flight while the zero-point test below synchronises the workgroup
+
+    const bool need_sx = __syncthreads_or((oc < a.OC && zwp != 0.0f) ? 1 : 0) != 0;   // workgroup-uniform
+    if (need_sx) {
+        for (int i = tid; i < NTP; i += MF_THREADS) sxp[i] = 0;
+        __syncthreads();
+    }
+
     auto stage_x = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
@@ -819,7 +823,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
     };
 
     const int n_stages = (a.IC + CK - 1) / CK;
-    issue_x(0);
     for (int s = 0; s < n_stages - 1; ++s) stage(s, std::true_type{});
     stage(n_stages - 1, std::false_type{});
 
@@ -869,7 +872,7 @@ void launch_mfma_cfg0(const MfmaArgs &a, int niw, int ns, int KK, bool x8, unsig
 void launch_mfma_cfg1(const MfmaArgs &a, int niw, int ns, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_cfg2(const MfmaArgs &a, int niw, int ns, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_smallic(const MfmaArgs &a, int cfg, unsigned blocks, size_t lds, hipStream_t s);
-void launch_mfma_flat(const MfmaArgs &a, int cfg, int ns, bool wraw, unsigned blocks, size_t lds, hipStream_t s);
+void launch_mfma_flat(const MfmaArgs &a, int cfg, int niw, int ns, bool wraw, unsigned blocks, size_t lds, hipStream_t s);
 
 #define QE_MFMA_K(WM, WN, NIW, KKT, X8, NS) \
     hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, NIW, KKT, X8, NS>), dim3(blocks), dim3(MF_THREADS), lds, s, a)
