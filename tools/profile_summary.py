@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_round.sh run into profiles/<tag>_kernel_stats.csv and profiles/<tag>_traffic.json."""
+import csv, glob, json, os, sys
+out, tag = sys.argv[1], sys.argv[2]
+os.makedirs("profiles", exist_ok=True)
+steps = 7  # --steps 5 --warmup 2
+# kernel stats
+f = glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True)
+if f:
+    rows = list(csv.DictReader(open(f[0])))
+    with open("profiles/%s_kernel_stats.csv" % tag, "w") as w:
+        w.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline (7 steps incl. warm-up)\n")
+        w.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
+        for r in rows:
+            n = r["Name"]
+            n = n if len(n) <= 110 else n[:107] + "..."
+            w.write('"%s",%s,%s,%s,%s,%s,%s\n' % (n, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]))
+    conv = [r for r in rows if "conv_mfma" in r["Name"] and "prep" not in r["Name"]]
+    prep = [r for r in rows if "prep" in r["Name"]]
+    tot_conv = sum(float(r["TotalDurationNs"]) for r in conv)
+    calls_conv = sum(int(r["Calls"]) for r in conv)
+    tot_prep = sum(float(r["TotalDurationNs"]) for r in prep)
+    print("conv kernels: %d launches, %.3f ms per step, avg %.1f us per launch; prep: %.3f ms per step" % (
+        calls_conv, tot_conv / steps / 1e6, tot_conv / calls_conv / 1e3, tot_prep / steps / 1e6))
+def pmc_sum(kind, counter):
+    tot, n = 0.0, 0
+    for f in glob.glob(out + "/%s/**/*counter_collection.csv" % kind, recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "conv_mfma" in r["Kernel_Name"] and "prep" not in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                tot += float(r["Counter_Value"]); n += 1
+    return tot, n
+fs, nf = pmc_sum("fetch", "FETCH_SIZE")
+ws, nw = pmc_sum("write", "WRITE_SIZE")
+if nf and nw:
+    # KiB units; gfx950 FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced reads -> doubled
+    fetch_b = 2.0 * fs * 1024 / nf
+    write_b = ws * 1024 / nw
+    d = {"tag": tag, "launches_profiled": nf, "fetch_size_kib_per_launch_raw": fs / nf, "write_size_kib_per_launch": ws / nw,
+         "fetch_bytes_per_launch_corrected_x2": fetch_b, "write_bytes_per_launch": write_b,
+         "hbm_bytes_per_launch": fetch_b + write_b,
+         "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE) over python bench.py --steps 5 --warmup 2; conv_mfma_* kernels only; "
+                 "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B for 16 B/lane streams)"}
+    json.dump(d, open("profiles/%s_traffic.json" % tag, "w"), indent=1)
+    json.dump(d, open("profiles/traffic.json", "w"), indent=1)
+    print(json.dumps(d))
