@@ -176,7 +176,8 @@ struct MfmaPlan {
     int TH = 0, ni = 0, niw = 0, IHT = 0, IWP = 0, ROWMUL = 1, COLMUL = 1;
     bool smallic = false;
     int GI = 1, NS = 1;
-    bool flat = false, wraw = false;
+    bool flat = false, wraw = false, ws = false;
+    int PADW = 0;
     size_t lds = 0;
     size_t wt_bytes = 0, ep_off = 0, ws_off = 0, total = 0;
 };
@@ -285,6 +286,26 @@ static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits, int w_bits)
         for (int i = 0; i < 3; ++i)
             if (kNiw[p.cfg][i] > 0 && kNiw[p.cfg][i] * kWN[p.cfg] >= p.ni) p.niw = kNiw[p.cfg][i];
         p.wt_bytes = (size_t)p.KK * p.NG * p.OCP * 16;
+        // 3x3, 8-bit activations, 128-channel tiles: the warp-specialised kernel (producer/consumer
+        // waves, double-buffered halo image).
+        const char *ws_env = getenv("QE_WS");
+        // Measured on ResNet-50 (A/B, tools/ab_env.sh QE_WS): it wins where a workgroup has little MFMA work
+        // per stage to hide its own fetch behind (7x7 maps: 0.068 -> 0.052-0.057 ms) and loses 5-15 % on the
+        // 14x14 / 28x28 / 56x56 layers, where two resident single-role workgroups overlap each other better
+        // than one specialised one (stamps: the consumer issues one MFMA per ~60 cycles; its weight loads queue
+        // behind the producers' HBM misses in the CU's in-order vector-memory path).  QE_WS=1 forces it on.
+        const bool ws_default = p.GI > 1 || p.OH * p.OW <= 64;
+        const bool ws_on = ws_env ? atoi(ws_env) != 0 : ws_default;
+        if (p.KK == 9 && sh->KW == 3 && x_bits == 8 && p.cfg == 0 && p.NS == 1 && ws_on) {
+            // stride 1 with padding 1: unpadded LDS rows (conflict-free fragment reads) + lane masks
+            const char *np_env = getenv("QE_WS_NOPAD");
+            const bool nopad = sh->stride == 1 && sh->padding == 1 && (np_env && atoi(np_env) == 1);   // off by default
+            const int iwp = nopad ? sh->W : p.IWP;
+            const int gd = nopad ? sh->padding : 0;
+            const size_t gsz = (size_t)p.GI * p.IHT * iwp + 2 * gd;
+            const size_t lds = ((size_t)4 * gsz + MF_TRASH) * 16 + gsz * 4;
+            if (lds <= (size_t)MF_MAX_LDS) { p.ws = true; p.lds = lds; p.IWP = iwp; p.PADW = nopad ? 0 : sh->padding; }
+        }
     }
     if (p.flat && p.wraw) { p.total = 0; p.ok = true; return p; }
     p.ep_off = align_up(p.wt_bytes, 256);
@@ -345,6 +366,7 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     a.OCP = p.OCP; a.NG = p.NG; a.NCH = p.NCH;
     a.TH = p.TH; a.tiles_h = (p.OH + p.TH - 1) / p.TH;
     a.GI = p.GI;
+    a.PADW = p.ws ? p.PADW : sh->padding;
     a.dbg = g_mfma_dbg;
     a.w_raw = w->data; a.w_scale = w->scale; a.w_zero = w->zero; a.x_scale = x->scale; a.bias = bias;
     a.w_bits = w->n_bits; a.w_sign = w->sign; a.w_per_tensor = (w->n_param == 1);
@@ -368,6 +390,15 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     const bool x8 = x->n_bits == 8;
     if (p.flat) {
         launch_mfma_flat(a, p.cfg, p.niw, p.NS, p.wraw, (unsigned)blocks, p.lds, s);
+        QE_LAUNCH_CHECK();
+        return QE_OK;
+    }
+    if (p.ws) {
+        {
+            const int units = p.GI * p.IHT * ((sh->W + 3) / 4);
+            const int split = units <= 64 ? 4 : (units <= 128 ? 2 : 1);   // idle producer threads take channel slices
+            launch_mfma_ws(a, p.niw, split, (unsigned)blocks, p.lds, s);
+        }
         QE_LAUNCH_CHECK();
         return QE_OK;
     }

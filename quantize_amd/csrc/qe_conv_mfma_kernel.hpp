@@ -31,6 +31,7 @@ struct MfmaArgs {
     int TH, tiles_h, n_pix_tiles, n_oc_tiles;
     int IHT, IWP, ROWMUL, COLMUL, ni;
     int GI;                    // whole images per pixel tile (> 1 only for small feature maps, TH == OH)
+    int PADW;                  // ws kernel: left padding columns materialised in LDS (0 = unpadded rows + lane masks)
     unsigned long long *dbg;   // diagnostic builds (-DQE_STAMP) only: per-wave phase cycle sums
     // raw operands, used by the flat 1x1 kernel (it builds its epilogue constants itself)
     const uint8_t *w_raw;      // packed OIHW weights as the caller passed them
@@ -501,6 +502,309 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs
 }
 
 // ---------------------------------------------------------------------------------------------
+// Warp-specialised 3x3 kernel (8-bit activations): the MFMA-bound layers.
+// In the halo kernel every wave alternates between fetch/transposes and MFMA, so a SIMD's matrix
+// pipe idles during half of each wave's life (measured: MFMA phase 43 % of the wave time on
+// 256->256 3x3 at 14x14).  Here a workgroup is 8 waves with fixed roles:
+//   waves 0-3  consumers: weight fragments (L2 -> VGPR) + ds_read_b128 + v_mfma, nothing else.  Their
+//              vmcnt queue only ever holds weight loads, so afr[tap] is re-requested for the NEXT
+//              stage right after its last MFMA of this stage: the weights of a stage are always a
+//              full stage old when they are needed, with no extra registers.
+//   waves 4-7  producers: activation fetch (global -> VGPR), 4x4 byte transposes, LDS writes of stage
+//              s+1 into the other half of a double-buffered halo image while stage s is consumed.
+// One s_barrier per stage hands buffer (s+1)%2 to the consumers and buffer s%2 back to the producers.
+// 512 threads x <= 256 VGPRs = one workgroup per CU, one consumer wave per SIMD (a single wave with 7
+// independent accumulators can keep the matrix pipe issuing back to back).
+// Tile, LDS image layout, operand roles and epilogue are the halo kernel's (4x1 consumer waves).
+// ---------------------------------------------------------------------------------------------
+template <int NIW, int KKT, int SPLIT, bool NOPAD>
+__global__ __launch_bounds__(2 * MF_THREADS, 2) void conv_mfma_ws_kernel(const MfmaArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint4 *Xs = reinterpret_cast<uint4 *>(smem);
+
+    constexpr int WM = 4, WN = 1, MT = 128;
+    constexpr int KW_T = (KKT == 9) ? 3 : 1;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave < 4;
+    const int cw = wave & 3;                 // index inside the role
+    const int col = lane & 31, h = lane >> 5;
+
+    int pt, ot, th;
+    TileGeom g;
+    if (!decode_tile(a, pt, ot, g, th)) return;
+    const int NT = g.NT;
+    const int ih0 = g.oh0 * a.stride - a.pad;
+    // Unpadded-row mode (PADW = 0, stride-1 layers): LDS rows hold exactly W pixels, so the 32 lanes of a
+    // column tile read 32 CONSECUTIVE 16-byte slots for every tap (conflict-free; with W+2-pixel rows the
+    // 14- and 7-pixel-wide maps hit every bank twice and the kernel is LDS-bound).  A tap that would fall
+    // left/right of the image then reads a neighbouring row's pixel: those lanes zero their fragment.
+    const int GD = NOPAD ? a.pad : 0;        // guard slots in front of / behind each group image (PADW = 0 iff NOPAD)
+    const int ISZ = a.IHT * a.IWP;
+    const int GSZ = a.GI * ISZ + 2 * GD;     // slots of one 16-channel group
+    const int BUF = 2 * GSZ;                 // uint4 slots of one buffer (2 groups = 32 channels)
+    const int trash = 2 * BUF + lane;
+    int *sxp = reinterpret_cast<int *>(Xs + 2 * BUF + MF_TRASH);
+
+    for (int i = tid; i < 2 * BUF; i += 2 * MF_THREADS) Xs[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < GSZ; i += 2 * MF_THREADS) sxp[i] = 0;
+
+    int zw_local = 0;
+    if (tid < MT) zw_local = (a.ep[a.OCP + ot * MT + tid] != 0.0f) ? 1 : 0;
+    const bool need_sx = __syncthreads_or(zw_local) != 0;  // also orders the LDS zero fill
+    const int n_stages = a.NCH;
+#ifdef QE_STAMP
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = qe_stamp();
+    const unsigned long long tstart = tprev;
+#endif
+
+    if (!consumer) {
+        // ================================ producers ==========================================
+        // The 256 producer threads split a 32-channel chunk SPLIT ways (32 / SPLIT channels per thread):
+        // small halo tiles (14x14: 64 pixel quads) would otherwise leave three of the four producer
+        // waves idle and put all 32 loads + transposes of a stage on one wave.
+        constexpr int CPT = 32 / SPLIT;            // channels per thread: 32, 16 or 8
+        constexpr int TPS = MF_THREADS / SPLIT;    // threads per channel slice
+        const int ptid = tid - MF_THREADS;
+        const int sub = __builtin_amdgcn_readfirstlane(ptid / TPS);   // wave-uniform channel slice
+        const int NQ = (a.W + 3) >> 2;
+        const int HW = a.H * a.W;
+        const uint8_t *xi = a.x + (int64_t)g.n0 * a.IC * HW;
+        int u_off, u_sh = 0, u_lds[4];
+        {
+            const int lt = ptid - sub * TPS;
+            const int gi = lt / (a.IHT * NQ);
+            const int rr = lt - gi * (a.IHT * NQ);
+            const int l = rr / NQ, iq = rr - l * NQ;
+            const int ih = ih0 + l * a.ROWMUL;
+            const bool ok = gi < a.GI && g.n0 + gi < a.N && ih >= 0 && ih < a.H;
+            int iw0 = 4 * iq;
+            if (iw0 + 4 > a.W) { u_sh = 8 * (iw0 + 4 - a.W); iw0 = a.W - 4; }
+            u_off = ok ? gi * a.IC * HW + ih * a.W + iw0 : 0;
+            if (!ok) u_sh = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iw = 4 * iq + j;
+                const int cl = iw + a.PADW;
+                const int clc = cl / a.COLMUL;
+                const bool pok = ok && iw < a.W && (clc * a.COLMUL == cl) && clc < a.IWP;
+                u_lds[j] = pok ? GD + (gi * a.IHT + l) * a.IWP + clc : -1;
+            }
+        }
+        const int ch0 = sub * CPT;                 // first channel of this thread's slice inside the chunk
+        // Register ring: the fetch of stage s+1+D is requested when stage s+1 is written to LDS, so a
+        // load has D stages (not one) to come back.  A 3x3 stage is ~1 us of MFMA work but an HBM/L2
+        // round trip under load is 2-3 us: with a one-stage lead the whole workgroup ran at memory
+        // latency per stage (measured).  Producers own few registers, so the ring is free.
+        constexpr int D = (CPT == 32) ? 2 : 4;
+        uint32_t d[D][CPT];
+        auto issue_x = [&](int c, auto slot) __attribute__((always_inline)) {
+            constexpr int S = decltype(slot)::value;
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) {
+                const int ic = c * 32 + ch0 + i;
+                const int icc = ic < a.IC ? ic : a.IC - 1;
+                uint32_t v;
+                __builtin_memcpy(&v, xi + (int64_t)icc * HW + (uint32_t)u_off, 4);
+                d[S][i] = v;
+            }
+        };
+        auto stage_x = [&](int c, int buf, auto slot) __attribute__((always_inline)) {
+            constexpr int S = decltype(slot)::value;
+            uint32_t e[CPT];
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) e[i] = (d[S][i] >> u_sh) ^ 0x80808080u;
+            uint32_t o[4][CPT / 4];
+#pragma unroll
+            for (int m = 0; m < CPT / 4; ++m)
+                transpose4x4(e[4 * m], e[4 * m + 1], e[4 * m + 2], e[4 * m + 3], o[0][m], o[1][m], o[2][m], o[3][m]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // byte address of this thread's channel slice inside the pixel's two 16-byte vectors
+                if constexpr (CPT == 32) {
+                    const int i0 = u_lds[j] >= 0 ? buf * BUF + u_lds[j] : trash;
+                    const int i1 = u_lds[j] >= 0 ? buf * BUF + GSZ + u_lds[j] : trash;
+                    Xs[i0] = make_uint4(o[j][0], o[j][1], o[j][2], o[j][3]);
+                    Xs[i1] = make_uint4(o[j][4], o[j][5], o[j][6], o[j][7]);
+                } else if constexpr (CPT == 16) {
+                    const int i0 = u_lds[j] >= 0 ? buf * BUF + sub * GSZ + u_lds[j] : trash;
+                    Xs[i0] = make_uint4(o[j][0], o[j][1], o[j][2], o[j][3]);
+                } else {
+                    const int i0 = u_lds[j] >= 0 ? buf * BUF + (sub >> 1) * GSZ + u_lds[j] : trash;
+                    uint2 *p2 = reinterpret_cast<uint2 *>(&Xs[i0]) + (sub & 1);
+                    *p2 = make_uint2(o[j][0], o[j][1]);
+                }
+            }
+            if (need_sx) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int sum = 0;
+#pragma unroll
+                    for (int m = 0; m < CPT / 4; ++m) {
+                        const int nv = a.IC - (c * 32 + ch0 + 4 * m);
+                        const int ones = nv >= 4 ? 0x01010101 : (nv <= 0 ? 0 : (0x01010101 & ((1 << (8 * nv)) - 1)));
+                        sum = __builtin_amdgcn_sdot4((int)o[j][m], ones, sum, false);
+                    }
+                    if (u_lds[j] >= 0) atomicAdd(&sxp[u_lds[j]], sum);
+                }
+            }
+        };
+        // Stage c always lives in ring slot c % D.  Chunk indices past the end are clamped by issue_x's
+        // channel clamp (they re-read the last channels and are never staged), which keeps every load
+        // of the steady-state loop unconditional.
+        // prologue: stages 0..D-1 requested, stage 0 staged into buffer 0
+        issue_x(0, std::integral_constant<int, 0>{});
+        if constexpr (D > 1) issue_x(1, std::integral_constant<int, 1 % D>{});
+        if constexpr (D > 2) issue_x(2, std::integral_constant<int, 2 % D>{});
+        if constexpr (D > 3) issue_x(3, std::integral_constant<int, 3 % D>{});
+        stage_x(0, 0, std::integral_constant<int, 0>{});
+        issue_x(D, std::integral_constant<int, 0>{});
+        QE_ST(0);                       // prologue
+        __syncthreads();                // (P) buffer 0 is complete
+        QE_ST(2);
+        // consumer stage s <-> producer iteration s: write X(s+1) (slot (s+1)%D) into buffer (s+1)%2,
+        // then request X(s+1+D) into the slot just freed.  Unrolled by D so the slots are static.
+        auto iter = [&](int s, auto slot) __attribute__((always_inline)) {
+            if (s + 1 < n_stages) stage_x(s + 1, (s + 1) & 1, slot);   // LDS work only behind the branch
+            QE_ST(1);   // wait X + transpose + LDS writes
+            issue_x(s + 1 + D, slot);
+            QE_ST(3);   // X issue
+            __syncthreads();
+            QE_ST(2);   // barrier
+        };
+        int s = 0;
+        for (; s + D <= n_stages; s += D) {
+            iter(s, std::integral_constant<int, 1 % D>{});
+            if constexpr (D > 1) iter(s + 1, std::integral_constant<int, 2 % D>{});
+            if constexpr (D > 2) iter(s + 2, std::integral_constant<int, 3 % D>{});
+            if constexpr (D > 3) iter(s + 3, std::integral_constant<int, 0>{});
+        }
+        // tail: n_stages % D remaining consumer stages
+        if (s < n_stages) { iter(s, std::integral_constant<int, 1 % D>{}); ++s; }
+        if constexpr (D > 2) {
+            if (s < n_stages) { iter(s, std::integral_constant<int, 2 % D>{}); ++s; }
+            if (s < n_stages) { iter(s, std::integral_constant<int, 3 % D>{}); ++s; }
+        }
+#ifdef QE_STAMP
+        if (a.dbg != nullptr && lane == 0) {
+            unsigned long long *o = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 10;
+            for (int i = 0; i < 8; ++i) o[i] = st[i];
+            o[8] = tprev - tstart;
+            o[9] = tstart;
+        }
+#endif
+        return;
+    }
+
+    // ==================================== consumers ==========================================
+    const int RS = a.stride / a.ROWMUL, CS = a.stride / a.COLMUL;
+    int pixidx[NIW];
+    unsigned km[NIW];        // bit kw set: tap column kw of this lane's pixel is inside the image row
+#pragma unroll
+    for (int t = 0; t < NIW; ++t) {
+        const int q = t * 32 + col;
+        const int gi = (a.GI > 1) ? q / g.OHWt : 0;
+        const int rq = q - gi * g.OHWt;
+        const int r = rq / a.OW, c = rq - r * a.OW;
+        // origin of the receptive field: LDS column c*CS - GD (the guard slots absorb the -GD of row 0)
+        pixidx[t] = h * GSZ + ((q < NT) ? gi * ISZ + (r * RS) * a.IWP + c * CS : 0);
+        unsigned m = 0;
+#pragma unroll
+        for (int kw = 0; kw < KW_T; ++kw) {
+            const int iw = c * a.stride - a.pad + kw;
+            if (!NOPAD || (iw >= 0 && iw < a.W)) m |= 1u << kw;
+        }
+        km[t] = m;
+    }
+    const int8_t *a_base = a.wt + (int64_t)(ot * MT + cw * 32) * 16;   // wave-uniform
+    const uint32_t a_voff = (uint32_t)(h * a.OCP + col) * 16u;
+    const int64_t grp_stride = (int64_t)a.OCP * 16;
+    const int64_t tap_stride = (int64_t)a.NG * grp_stride;
+
+    v16i acc[NIW];
+#pragma unroll
+    for (int t = 0; t < NIW; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0;
+    }
+    v4i afr[KKT];
+#pragma unroll
+    for (int tap = 0; tap < KKT; ++tap) afr[tap] = *reinterpret_cast<const v4i *>(a_base + tap * tap_stride + a_voff);
+
+    QE_ST(0);                           // consumer prologue (setup + first weight requests)
+    __syncthreads();                    // (P) buffer 0 is complete
+    QE_ST(2);
+    // B fragments run one tap ahead of the MFMAs (7 ds_read_b128 interleaved 1:1 with the 7 MFMAs of
+    // the previous tap): every LDS read is issued >= 7 MFMA slots before its use, so the single
+    // consumer wave of a SIMD issues MFMAs back to back.
+    v4i bq[2][NIW];
+    for (int s = 0; s < n_stages; ++s) {
+        const int boff = (s & 1) * BUF;
+        const int sn = s + 1 < n_stages ? s + 1 : s;       // the last stage re-requests its own weights (9 L2 hits)
+        const int8_t *a_n = a_base + (int64_t)(2 * sn) * grp_stride;
+#pragma unroll
+        for (int t = 0; t < NIW; ++t) bq[0][t] = *reinterpret_cast<const v4i *>(&Xs[pixidx[t] + boff]);
+#pragma unroll
+        for (int tap = 0; tap < KKT; ++tap) {
+            const int cur = tap & 1, nxt = cur ^ 1;
+            if (tap + 1 < KKT) {
+                const int off = boff + ((tap + 1) / KW_T) * a.IWP + ((tap + 1) % KW_T);
+#pragma unroll
+                for (int t = 0; t < NIW; ++t) bq[nxt][t] = *reinterpret_cast<const v4i *>(&Xs[pixidx[t] + off]);
+            }
+#pragma unroll
+            for (int t = 0; t < NIW; ++t) {
+                v4i bf = bq[cur][t];
+                if constexpr (NOPAD && (KW_T == 3)) {
+                    if ((tap % KW_T) != 1) {             // 3x3 / pad 1: the centre column is always inside
+                        const int keep = ((km[t] >> (tap % KW_T)) & 1u) ? -1 : 0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) bf[k] &= keep;
+                    }
+                }
+                acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[tap], bf, acc[t], 0, 0, 0);
+            }
+            afr[tap] = *reinterpret_cast<const v4i *>(a_n + tap * tap_stride + a_voff);   // next stage's fragment
+            if (tap + 1 < KKT) {
+#pragma unroll
+                for (int t = 0; t < NIW; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // taps stay in order: the scheduler may not regroup the 63 MFMAs
+        }
+        QE_ST(4);   // MFMA phase
+        __syncthreads();
+        QE_ST(5);   // barrier
+    }
+
+    int sxs[NIW];
+#pragma unroll
+    for (int t = 0; t < NIW; ++t) {
+        sxs[t] = 0;
+        if (need_sx) {
+            const int pbase = pixidx[t] - h * GSZ;
+            for (int tap = 0; tap < KKT; ++tap)
+                if ((km[t] >> (tap % KW_T)) & 1u) sxs[t] += sxp[pbase + (tap / KW_T) * a.IWP + (tap % KW_T)];
+        }
+    }
+    mfma_epilogue<WM, WN, NIW>(a, acc, sxs, need_sx, g, ot, cw, 0, col, h, KKT);
+#ifdef QE_STAMP
+    QE_ST(7);
+    if (a.dbg != nullptr && lane == 0) {
+        unsigned long long *o = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 10;
+        for (int i = 0; i < 8; ++i) o[i] = st[i];
+        o[8] = tprev - tstart;
+        o[9] = tstart;
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
 // Small-IC variant (IC <= 4, KW <= 8, 8-bit activations): the stem convolution (3 -> 64, 7x7/2).
 // Padding 3 channels to a 32-channel chunk would waste 10x the MFMA work and LDS, so K is laid out
 // as (kh) x [kw 0..7][ic 0..3]: one 32-deep MFMA step per kernel row.  LDS holds the halo tile
@@ -872,6 +1176,7 @@ void launch_mfma_cfg0(const MfmaArgs &a, int niw, int ns, int KK, bool x8, unsig
 void launch_mfma_cfg1(const MfmaArgs &a, int niw, int ns, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_cfg2(const MfmaArgs &a, int niw, int ns, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_smallic(const MfmaArgs &a, int cfg, unsigned blocks, size_t lds, hipStream_t s);
+void launch_mfma_ws(const MfmaArgs &a, int niw, int split, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_flat(const MfmaArgs &a, int cfg, int niw, int ns, bool wraw, unsigned blocks, size_t lds, hipStream_t s);
 
 #define QE_MFMA_K(WM, WN, NIW, KKT, X8, NS) \

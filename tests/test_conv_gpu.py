@@ -241,3 +241,26 @@ def test_conv_error_messages(engine):
         engine.quantconv2d_float_input(torch.zeros(1, 4, 2, 2, device=DEV), wp, wd, one, one, None, 1, 0)
     y = engine.quantconv2d(xp, xd, one, 0 * one, wp, wd, one, 0 * one, None, 1, 1)
     assert tuple(y.shape) == (1, 6, 8, 8) and float(y.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("env", [{"QE_WS": "1"}, {"QE_WS": "1", "QE_WS_NOPAD": "1"}, {"QE_WS": "0"}, {"QE_FLAT_NIW": "4"}])
+def test_kernel_variants_forced_by_env(engine, env):
+    """The tuning knobs select other kernel variants (warp-specialised 3x3 with padded / unpadded LDS rows,
+    single-role 3x3, 128-pixel flat tiles); every variant must meet the same parity bar."""
+    import os
+    rng = np.random.RandomState(17)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        for shp in [(2, 256, 14, 14, 256, 3, 1, 1), (3, 128, 28, 28, 128, 3, 1, 1), (4, 160, 7, 7, 130, 3, 1, 1),
+                    (2, 128, 14, 14, 192, 3, 2, 1), (2, 256, 28, 28, 160, 1, 1, 0)]:
+            for zeros in (False, True):
+                case = _random_case(rng, *shp, 8, 1, 8, 0 if zeros else 1, w_pc=True, a_pc=False, zeros=zeros, bias=True)
+                y, o32, o64 = _run_case(engine, case, via_capi=True)
+                _assert_conv_close(y, o64, o32, "%s %s zeros=%s" % (env, shp, zeros))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

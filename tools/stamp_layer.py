@@ -23,12 +23,17 @@ for idx in [int(v) for v in sys.argv[1:]]:
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     layer.run(st); torch.cuda.synchronize()
     buf.zero_(); layer.run(st); torch.cuda.synchronize()
-    d = buf.view(-1, 10)
-    d = d[d[:, 8] > 0].double()
-    print("layer %d %s %s: %d waves" % (idx, specs[idx].name, tuple(specs[idx][1:]), d.shape[0]))
-    tot = d[:, 8].mean().item()
-    for i in range(8):
-        m = d[:, i].mean().item()
-        print("   %-26s %9.0f cyc  %5.1f%%" % (names[i], m, 100 * m / tot))
-    print("   %-26s %9.0f cyc; span first->last start %.0f" % ("total per wave", tot, (d[:, 9].max() - d[:, 9].min()).item()))
+    dall = buf.view(-1, 10)
+    groups = [("all waves", dall)]
+    if os.environ.get("QE_STAMP_WS"):   # warp-specialised kernel: 8 waves per block, 0-3 consumers, 4-7 producers
+        d8 = dall.view(-1, 8, 10)
+        groups = [("consumers", d8[:, :4].reshape(-1, 10)), ("producers", d8[:, 4:].reshape(-1, 10))]
+    for gname, d in groups:
+        d = d[d[:, 8] > 0].double()
+        print("layer %d %s %s [%s]: %d waves" % (idx, specs[idx].name, tuple(specs[idx][1:]), gname, d.shape[0]))
+        tot = d[:, 8].mean().item()
+        for i in range(8):
+            m = d[:, i].mean().item()
+            print("   %-26s %9.0f cyc  %5.1f%%" % (names[i], m, 100 * m / tot))
+        print("   %-26s %9.0f cyc; span first->last start %.0f" % ("total per wave", tot, (d[:, 9].max() - d[:, 9].min()).item()))
     L.qe_debug_set_stamp_buffer(None)
