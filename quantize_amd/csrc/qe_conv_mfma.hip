@@ -176,7 +176,7 @@ struct MfmaPlan {
     int TH = 0, ni = 0, niw = 0, IHT = 0, IWP = 0, ROWMUL = 1, COLMUL = 1;
     bool smallic = false;
     int GI = 1, NS = 1;
-    bool flat = false, wraw = false, ws = false;
+    bool flat = false, wraw = false, ws = false, s2 = false;
     int PADW = 0;
     size_t lds = 0;
     size_t wt_bytes = 0, ep_off = 0, ws_off = 0, total = 0;
@@ -209,7 +209,25 @@ static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits, int w_bits)
     const int NQ = (sh->W + 3) / 4;
     const int P = sh->H * sh->W;
     p.flat = p.KK == 1 && sh->stride == 1 && sh->padding == 0 && x_bits == 8 && (P % 4) == 0 && P >= 64 && sh->IC >= 16;
-    if (p.flat) {
+    // 1x1 / stride 2 / no padding (the downsample branches): same GEMM over the flat OUTPUT pixels, the
+    // staging keeps the even columns of the even input rows.  224-pixel tiles must hold whole output rows.
+    const int POUT = p.OH * p.OW;
+    if (!p.flat && p.KK == 1 && sh->stride == 2 && sh->padding == 0 && x_bits == 8 && p.cfg == 0 && sh->IC >= 64 &&
+        (POUT % 4) == 0 && POUT >= 64 && 224 % p.OW == 0 && sh->W >= 16 && (sh->W % 4) == 0 &&
+        !(getenv("QE_FLAT_S2") && atoi(getenv("QE_FLAT_S2")) == 0)) {
+        const int rt = 224 / p.OW, seg = (sh->W + 15) / 16;
+        if (64 * rt * seg <= 8 * MF_THREADS) { p.flat = true; p.s2 = true; }
+    }
+    if (p.flat && p.s2) {
+        const int ntp = 224, rstr = 224;
+        p.NS = 2;
+        p.lds = std::max((size_t)64 * rstr, (size_t)4 * 32 * 36 * 4) + (size_t)ntp * 4;
+        p.TH = 1; p.ni = 7; p.niw = 7;
+        p.NCH = (sh->IC + 31) / 32; p.NG = 2 * p.NCH;
+        p.wraw = (w_bits == 8) && (sh->IC % 16) == 0;
+        p.wt_bytes = p.wraw ? 0 : (size_t)p.NG * p.OCP * 16;
+        p.IHT = (POUT + ntp - 1) / ntp;   // pixel tiles per image
+    } else if (p.flat) {
         // 1x1 / stride 1 / no padding: GEMM over the flat pixel index (conv_mfma_flat_kernel)
         int tiles = max_tiles;
         if (p.cfg == 0) {
@@ -389,7 +407,7 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
     const bool x8 = x->n_bits == 8;
     if (p.flat) {
-        launch_mfma_flat(a, p.cfg, p.niw, p.NS, p.wraw, (unsigned)blocks, p.lds, s);
+        launch_mfma_flat(a, p.cfg, p.niw, p.NS, p.wraw, p.s2, (unsigned)blocks, p.lds, s);
         QE_LAUNCH_CHECK();
         return QE_OK;
     }

@@ -4,7 +4,7 @@
 namespace qe {
 
 #define QE_FLAT(WM, WN, NIW, NS, WRAW) \
-    hipLaunchKernelGGL((conv_mfma_flat_kernel<WM, WN, NIW, NS, WRAW>), dim3(blocks), dim3(MF_THREADS), lds, s, a)
+    hipLaunchKernelGGL((conv_mfma_flat_kernel<WM, WN, NIW, NS, WRAW, false>), dim3(blocks), dim3(MF_THREADS), lds, s, a)
 
 #define QE_FLAT_NS(WM, WN, NIW)                                     \
     do {                                                            \
@@ -19,8 +19,13 @@ namespace qe {
         }                                                           \
     } while (0)
 
-void launch_mfma_flat(const MfmaArgs &a, int cfg, int niw, int ns, bool wraw, unsigned blocks, size_t lds, hipStream_t s)
+void launch_mfma_flat(const MfmaArgs &a, int cfg, int niw, int ns, bool wraw, bool s2, unsigned blocks, size_t lds, hipStream_t s)
 {
+    if (s2) {   // stride-2 1x1: 224-pixel tiles, 64-channel stages, 128-channel workgroups only
+        if (wraw) hipLaunchKernelGGL((conv_mfma_flat_kernel<4, 1, 7, 2, true, true>), dim3(blocks), dim3(MF_THREADS), lds, s, a);
+        else      hipLaunchKernelGGL((conv_mfma_flat_kernel<4, 1, 7, 2, false, true>), dim3(blocks), dim3(MF_THREADS), lds, s, a);
+        return;
+    }
     switch (cfg) {
         case 0:
             if (niw == 4) QE_FLAT_NS(4, 1, 4); else QE_FLAT_NS(4, 1, 7);

@@ -956,7 +956,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_smallic_kernel(const 
 // ---------------------------------------------------------------------------------------------
 typedef int v2i __attribute__((ext_vector_type(2)));
 
-template <int WM, int WN, int NIW, int NS, bool WRAW>
+template <int WM, int WN, int NIW, int NS, bool WRAW, bool S2>
 __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const MfmaArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -967,7 +967,10 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
     constexpr int RSTR = 32 * (NTILES | 1);     // LDS row stride: odd multiple of 32 B
     constexpr int CK = 32 * NS;                 // channels per stage
     constexpr int SEGS = NTP / 16;              // 16-pixel pieces per channel row
-    constexpr int PPT = (CK * SEGS + MF_THREADS - 1) / MF_THREADS;  // pieces per thread per stage
+    // S2 (1x1, stride 2, no padding): the GEMM runs over the flat OUTPUT pixels; a piece is 16 input bytes of
+    // an even input row, of which the 8 even columns are kept.  Pieces per thread then depend on the row
+    // geometry (rows x segments of the tile): 8 slots cover the supported shapes (host checks).
+    constexpr int PPT = S2 ? 8 : (CK * SEGS + MF_THREADS - 1) / MF_THREADS;  // pieces per thread per stage
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -975,7 +978,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
     const int wm = wave % WM, wn = wave / WM;
     const int col = lane & 31, h = lane >> 5;
 
-    const int P = a.H * a.W;                    // == OH*OW
+    const int P = S2 ? a.OH * a.OW : a.H * a.W;   // output pixels per image (== input pixels unless S2)
+    const int PIN = a.H * a.W;                    // input plane
     const int bid = blockIdx.x;
     const int grp_sz = 8 * a.n_oc_tiles;
     const int grp = bid / grp_sz, rem = bid - grp * grp_sz;
@@ -1003,7 +1007,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
     // piece e = tid + 256*i <-> (channel c = e / SEGS of the stage, 16-pixel segment s = e % SEGS).
     // The read is clamped to end at the plane's end (P >= 16); a clamped piece is rotated back by
     // whole dwords (P % 4 == 0), so no read ever leaves the tensor.
-    const int64_t img = (int64_t)n * a.IC * P;
+    const int64_t img = (int64_t)n * a.IC * PIN;
     const uint8_t *xi = a.x + img;
     int pc[PPT];          // channel within the stage
     int poff[PPT];        // clamped pixel offset inside the plane
@@ -1012,14 +1016,32 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
         const int e = tid + MF_THREADS * i;
-        const int c = e / SEGS, sg = e - c * SEGS;
-        const int px = p0 + 16 * sg;
-        const bool ok = c < CK && 16 * sg < NT;
-        const int pxc = px < P - 16 ? px : P - 16;
-        pc[i] = c < CK ? c : 0;
-        poff[i] = ok ? pxc : 0;
-        prot[i] = ok ? (px - pxc) >> 2 : 0;
-        plds[i] = ok ? c * RSTR + 16 * sg : -1;
+        if constexpr (!S2) {
+            const int c = e / SEGS, sg = e - c * SEGS;
+            const int px = p0 + 16 * sg;
+            const bool ok = c < CK && 16 * sg < NT;
+            const int pxc = px < P - 16 ? px : P - 16;
+            pc[i] = c < CK ? c : 0;
+            poff[i] = ok ? pxc : 0;
+            prot[i] = ok ? (px - pxc) >> 2 : 0;
+            plds[i] = ok ? c * RSTR + 16 * sg : -1;
+        } else {
+            // e <-> (channel c, output row r of the tile, 16-column input segment sg)
+            const int RT = NTP / a.OW;                       // output rows per tile (NTP % OW == 0)
+            const int SEG = (a.W + 15) >> 4;                 // 16-byte segments per input row
+            const int c = e / (RT * SEG);
+            const int rem2 = e - c * (RT * SEG);
+            const int r = rem2 / SEG, sg = rem2 - r * SEG;
+            const int oh = p0 / a.OW + r;
+            const bool ok = c < CK && oh < a.OH;
+            const int iw = 16 * sg;
+            const int iwc = iw < a.W - 16 ? iw : a.W - 16;   // never read past the row (W >= 16, W % 4 == 0)
+            pc[i] = c < CK ? c : 0;
+            poff[i] = ok ? (2 * oh) * a.W + iwc : 0;
+            prot[i] = ok ? (iw - iwc) >> 2 : 0;
+            // 8 output pixels of the piece start at column 8*sg; OW % 4 == 0 keeps both dwords whole
+            plds[i] = ok ? c * RSTR + r * a.OW + 8 * sg : -1;
+        }
     }
 
     // ---- weight fragment addressing -----------------------------------------------------------
@@ -1049,7 +1071,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
         for (int i = 0; i < PPT; ++i) {
             const int cg = s * CK + pc[i];
             const int cgc = cg < a.IC ? cg : a.IC - 1;
-            const uint8_t *src = xi + (uint32_t)(cgc * P + poff[i]);
+            const uint8_t *src = xi + (uint32_t)(cgc * PIN + poff[i]);
             __builtin_memcpy(&d[i], src, 16);     // one (4-byte aligned) global_load_dwordx4
         }
     };
@@ -1072,6 +1094,29 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
             const uint32_t r2 = rot == 0 ? v2 : (rot == 1 ? v3 : (rot == 2 ? v0 : v1));
             const uint32_t r3 = rot == 0 ? v3 : (rot == 1 ? v0 : (rot == 2 ? v1 : v2));
             const uint4 w4 = make_uint4(r0 ^ 0x80808080u, r1 ^ 0x80808080u, r2 ^ 0x80808080u, r3 ^ 0x80808080u);
+            if constexpr (S2) {
+                if (plds[i] >= 0) {
+                    // keep the even columns: bytes 0,2 of each dword
+                    const uint32_t e0 = __builtin_amdgcn_perm(w4.y, w4.x, 0x06040200u);
+                    const uint32_t e1 = __builtin_amdgcn_perm(w4.w, w4.z, 0x06040200u);
+                    const int colb = plds[i] - pc[i] * RSTR;             // pixel offset inside the tile
+                    const int ow0 = colb % a.OW;
+                    if ((a.OW & 3) == 0) {
+                        uint32_t *dst = reinterpret_cast<uint32_t *>(Xs + plds[i]);
+                        if (ow0 < a.OW) dst[0] = e0;
+                        if (ow0 + 4 < a.OW) dst[1] = e1;
+                    } else {
+                        // rows of the LDS image are not dword aligned (OW = 14): byte stores
+                        for (int j = 0; j < 8; ++j)
+                            if (ow0 + j < a.OW) Xs[plds[i] + j] = (uint8_t)((j < 4 ? e0 : e1) >> (8 * (j & 3)));
+                    }
+                    if (need_sx && s * CK + pc[i] < a.IC) {
+                        for (int j = 0; j < 8; ++j)
+                            if (ow0 + j < a.OW)
+                                atomicAdd(&sxp[colb + j], (int)(int8_t)((j < 4 ? e0 : e1) >> (8 * (j & 3))));
+                    }
+                }
+            } else
             if (plds[i] >= 0) {
                 *reinterpret_cast<uint4 *>(Xs + plds[i]) = w4;
                 if (need_sx && s * CK + pc[i] < a.IC) {
@@ -1177,7 +1222,7 @@ void launch_mfma_cfg1(const MfmaArgs &a, int niw, int ns, int KK, bool x8, unsig
 void launch_mfma_cfg2(const MfmaArgs &a, int niw, int ns, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_smallic(const MfmaArgs &a, int cfg, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_ws(const MfmaArgs &a, int niw, int split, unsigned blocks, size_t lds, hipStream_t s);
-void launch_mfma_flat(const MfmaArgs &a, int cfg, int niw, int ns, bool wraw, unsigned blocks, size_t lds, hipStream_t s);
+void launch_mfma_flat(const MfmaArgs &a, int cfg, int niw, int ns, bool wraw, bool s2, unsigned blocks, size_t lds, hipStream_t s);
 
 #define QE_MFMA_K(WM, WN, NIW, KKT, X8, NS) \
     hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, NIW, KKT, X8, NS>), dim3(blocks), dim3(MF_THREADS), lds, s, a)

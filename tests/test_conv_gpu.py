@@ -152,6 +152,8 @@ SWEEP_SHAPES = [
     (5, 64, 7, 7, 32, 3, 1, 1),     # several whole images per tile, last group partial
     (3, 96, 6, 6, 130, 1, 1, 0),
     (2, 160, 14, 14, 200, 1, 1, 0),  # multi-chunk stages with a padded last stage
+    (2, 128, 56, 56, 160, 1, 2, 0),  # stride-2 1x1 on the flat kernel (OW = 28)
+    (2, 96, 28, 28, 130, 1, 2, 0),   # stride-2 1x1, OW = 14 (byte-aligned LDS rows)
 ]
 
 
