@@ -28,7 +28,7 @@ void launch_mfma_flat(const MfmaArgs &a, int cfg, int niw, int ns, bool wraw, bo
     }
     switch (cfg) {
         case 0:
-            if (niw == 4) QE_FLAT_NS(4, 1, 4); else QE_FLAT_NS(4, 1, 7);
+            if (niw == 4) QE_FLAT_NS(4, 1, 4); else if (niw == 5) QE_FLAT_NS(4, 1, 5); else QE_FLAT_NS(4, 1, 7);
             break;
         case 1: QE_FLAT_NS(2, 2, 4); break;
         default: QE_FLAT_NS(1, 4, 2); break;

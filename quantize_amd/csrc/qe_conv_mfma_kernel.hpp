@@ -32,6 +32,7 @@ struct MfmaArgs {
     int IHT, IWP, ROWMUL, COLMUL, ni;
     int GI;                    // whole images per pixel tile (> 1 only for small feature maps, TH == OH)
     int PADW;                  // ws kernel: left padding columns materialised in LDS (0 = unpadded rows + lane masks)
+    int chunk;                 // consecutive pixel tiles one XCD takes before the next XCD's run starts
     unsigned long long *dbg;   // diagnostic builds (-DQE_STAMP) only: per-wave phase cycle sums
     // raw operands, used by the flat 1x1 kernel (it builds its epilogue constants itself)
     const uint8_t *w_raw;      // packed OIHW weights as the caller passed them
@@ -228,13 +229,23 @@ __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW
 // tile decode shared by both kernels.  XCD-aware block map: blocks b and b+8 share an XCD (and its
 // L2); the oc-tiles of one pixel tile get ids that differ by multiples of 8 so they read the same
 // activations from one L2.
+__device__ __forceinline__ void block_to_tile(const MfmaArgs &a, int &pt, int &ot)
+{
+    // XCD x = bid & 7 takes runs of `chunk` consecutive pixel tiles (all their oc tiles), run r of the XCD
+    // being global run 8*r + x.  chunk = 1 interleaves neighbouring tiles over the XCDs; a chunk of one or
+    // more whole images keeps the lines an L2 has in flight contiguous in memory, which the write-bound
+    // layers need (tools/probe_store_pattern2.hip: 4.2 -> 4.9 TB/s store-only at 28x28, 5.5 -> 5.8 at 56x56).
+    const int bid = blockIdx.x;
+    const int idx = bid >> 3;
+    const int j = idx / a.n_oc_tiles;
+    ot = idx - j * a.n_oc_tiles;
+    const int c = j / a.chunk;
+    pt = (c * 8 + (bid & 7)) * a.chunk + (j - c * a.chunk);
+}
+
 __device__ __forceinline__ bool decode_tile(const MfmaArgs &a, int &pt, int &ot, TileGeom &g, int &th)
 {
-    const int bid = blockIdx.x;
-    const int grp_sz = 8 * a.n_oc_tiles;
-    const int grp = bid / grp_sz, rem = bid - grp * grp_sz;
-    pt = grp * 8 + (rem & 7);
-    ot = rem >> 3;
+    block_to_tile(a, pt, ot);
     if (pt >= a.n_pix_tiles) return false;
     const int ng = pt / a.tiles_h;
     g.n0 = ng * a.GI;
@@ -972,6 +983,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
     // geometry (rows x segments of the tile): 8 slots cover the supported shapes (host checks).
     constexpr int PPT = S2 ? 8 : (CK * SEGS + MF_THREADS - 1) / MF_THREADS;  // pieces per thread per stage
 
+#ifdef QE_STAMP
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = qe_stamp();
+    const unsigned long long tstart = tprev;
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -980,11 +996,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
 
     const int P = S2 ? a.OH * a.OW : a.H * a.W;   // output pixels per image (== input pixels unless S2)
     const int PIN = a.H * a.W;                    // input plane
-    const int bid = blockIdx.x;
-    const int grp_sz = 8 * a.n_oc_tiles;
-    const int grp = bid / grp_sz, rem = bid - grp * grp_sz;
-    const int pt = grp * 8 + (rem & 7);
-    const int ot = rem >> 3;
+    int pt, ot;
+    block_to_tile(a, pt, ot);
     if (pt >= a.n_pix_tiles) return;
     const int n = pt / a.tiles_h;               // tiles_h = pixel tiles per image here
     const int p0 = (pt - n * a.tiles_h) * NTP;
@@ -1147,11 +1160,15 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
             if (icg >= NGR) f = v4i{0, 0, 0, 0};                  // channel padding of the last chunk
             wf[k] = f;
         }
+        QE_ST(0);   // prologue / weight requests
         // (2) activations of this stage: registers -> LDS
         stage_x(s);
+        QE_ST(1);   // wait X + LDS writes
         __syncthreads();
+        QE_ST(2);   // barrier 1
         // (3) next stage's activations in flight under the MFMA phase
         if constexpr (decltype(prefetch)::value) issue_x(s + 1);
+        QE_ST(3);   // X(s+1) issue
         // (4) MFMA: A = transposed activation fragment (rows = pixels), B = weights (cols = oc)
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
@@ -1168,7 +1185,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
                 acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xf, wf[k], acc[t], 0, 0, 0);
             }
         }
+        QE_ST(4);   // MFMA phase (incl. weight wait)
         __syncthreads();
+        QE_ST(5);   // barrier 2
     };
 
     const int n_stages = (a.IC + CK - 1) / CK;
@@ -1214,6 +1233,17 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);   // reads done before the next tile overwrites the patch
     }
+#ifdef QE_STAMP
+    QE_ST(6);       // epilogue: conversions, patch round trips, stores issued
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0): stores acknowledged
+    QE_ST(7);       // store drain
+    if (a.dbg != nullptr && lane == 0) {
+        unsigned long long *o = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 10;
+        for (int i = 0; i < 8; ++i) o[i] = st[i];
+        o[8] = tprev - tstart;
+        o[9] = tstart;
+    }
+#endif
 }
 
 // launchers, one translation unit per wave layout (qe_conv_mfma_i*.hip)

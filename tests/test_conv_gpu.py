@@ -245,7 +245,7 @@ def test_conv_error_messages(engine):
     assert tuple(y.shape) == (1, 6, 8, 8) and float(y.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("env", [{"QE_WS": "1"}, {"QE_WS": "1", "QE_WS_NOPAD": "1"}, {"QE_WS": "0"}, {"QE_FLAT_NIW": "4"}])
+@pytest.mark.parametrize("env", [{"QE_WS": "1"}, {"QE_WS": "1", "QE_WS_NOPAD": "1"}, {"QE_WS": "0"}, {"QE_FLAT_NIW": "4"}, {"QE_FLAT_NIW": "5"}, {"QE_FLAT_NIW": "7"}])
 def test_kernel_variants_forced_by_env(engine, env):
     """The tuning knobs select other kernel variants (warp-specialised 3x3 with padded / unpadded LDS rows,
     single-role 3x3, 128-pixel flat tiles); every variant must meet the same parity bar."""

@@ -14,7 +14,7 @@ args = A(); args.a_bits = 8; args.w_bits = 8; args.asymmetric = False
 L = capi.lib()
 dev = torch.device("cuda", 0)
 specs = resnet50.conv_layers()
-names = ["A issue", "X wait+transpose+LDSwr", "barrier1", "X(s+1) issue", "MFMA phase", "barrier2", "pre-epilogue", "epilogue", "total"]
+names = ["A issue / prologue", "X wait+transpose+LDSwr", "barrier1", "X(s+1) issue", "MFMA phase", "barrier2", "pre-epilogue | flat: epilogue", "epilogue | flat: store drain", "total"]
 for idx in [int(v) for v in sys.argv[1:]]:
     layer = Layer(idx, specs[idx], 256, dev, args, 0, capi, resnet50, torch)
     nblocks_max = 1 << 20
@@ -34,6 +34,6 @@ for idx in [int(v) for v in sys.argv[1:]]:
         tot = d[:, 8].mean().item()
         for i in range(8):
             m = d[:, i].mean().item()
-            print("   %-26s %9.0f cyc  %5.1f%%" % (names[i], m, 100 * m / tot))
-        print("   %-26s %9.0f cyc; span first->last start %.0f" % ("total per wave", tot, (d[:, 9].max() - d[:, 9].min()).item()))
+            print("   %-32s %9.0f cyc  %5.1f%%" % (names[i], m, 100 * m / tot))
+        print("   %-32s %9.0f cyc; span first->last start %.0f" % ("total per wave", tot, (d[:, 9].max() - d[:, 9].min()).item()))
     L.qe_debug_set_stamp_buffer(None)
