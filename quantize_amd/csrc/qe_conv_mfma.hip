@@ -176,7 +176,7 @@ struct MfmaPlan {
     int TH = 0, ni = 0, niw = 0, IHT = 0, IWP = 0, ROWMUL = 1, COLMUL = 1;
     bool smallic = false;
     int GI = 1, NS = 1;
-    bool flat = false, wraw = false, ws = false, s2 = false;
+    bool flat = false, wraw = false, ws = false, s2 = false, sm2 = false;
     int PADW = 0;
     size_t lds = 0;
     size_t wt_bytes = 0, ep_off = 0, ws_off = 0, total = 0;
@@ -262,7 +262,43 @@ static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits, int w_bits)
         p.IHT = (P + ntp - 1) / ntp;   // pixel tiles per image
     } else
     p.smallic = sh->IC <= 4 && sh->KW <= 8 && sh->KH <= 8 && x_bits == 8;
-    if (p.flat) {
+    // 3x3, 8-bit activations, more than 32 output channels: two strips per wave, weights through LDS
+    // (conv_mfma_sm2_kernel).  Measured against the halo / warp-specialised kernels on ResNet-50 (tools/ab_env.sh
+    // QE_SM2 0 1): 56x56 64->64 0.083 -> 0.068 ms, 14x14 256->256 0.050 -> 0.048, 28x28 +4 %, 7x7 maps and the
+    // stride-2 layers +15 % (the warp-specialised kernel / bigger halo tiles win there).  Default: stride 1 and a
+    // tile that is either 64 channels wide or a whole image; QE_SM2=1 forces it wherever it fits, QE_SM2=0 never.
+    const int sm2_env = getenv("QE_SM2") ? atoi(getenv("QE_SM2")) : -1;
+    if (!p.flat && !p.smallic && p.KK == 9 && sh->KW == 3 && sh->KH == 3 && x_bits == 8 && p.cfg <= 1 && sm2_env != 0) {
+        const int max_px = 32 * (p.cfg == 0 ? 8 : 16);
+        int GI = 1;
+        if (p.OH * p.OW <= max_px / 2) GI = std::max(1, std::min((int)sh->N, max_px / (p.OH * p.OW)));
+        int TH = (GI > 1) ? p.OH : std::min(p.OH, max_px / p.OW);
+        if (GI == 1 && TH >= 1) { const int nt = (p.OH + TH - 1) / TH; TH = (p.OH + nt - 1) / nt; }   // balanced row tiles
+        while (TH >= 1) {
+            const int IHT = (TH - 1) * sh->stride + 3, IWP = (p.OW - 1) * sh->stride + 3;
+            const int units = GI * IHT * NQ;
+            const size_t gsz = (size_t)GI * IHT * IWP;
+            const size_t wpieces = ((size_t)9 * 2 * p.MT + MF_THREADS - 1) / MF_THREADS * MF_THREADS;   // whole piece rounds
+            const size_t lds = align_up((2 * gsz + MF_TRASH) * 16 + gsz * 4, 16) + wpieces * 16;
+            if (units <= MF_THREADS && lds <= (size_t)MF_MAX_LDS_SM2) {
+                p.sm2 = true; p.GI = GI; p.TH = TH; p.IHT = IHT; p.IWP = IWP; p.lds = lds; p.NS = 1;
+                break;
+            }
+            if (GI > 1) { --GI; continue; }
+            --TH;
+        }
+        if (p.sm2) {
+            p.NCH = (sh->IC + 31) / 32;
+            p.NG = 2 * p.NCH;
+            p.ni = (p.GI * p.TH * p.OW + 31) / 32;
+            p.niw = 4;
+            p.wt_bytes = (size_t)p.KK * p.NG * p.OCP * 16;
+            if ((int64_t)p.wt_bytes >= (1ll << 31)) p.sm2 = false;
+            if (sm2_env < 0 && !(sh->stride == 1 && p.GI == 1 && (p.cfg == 1 || p.TH == p.OH))) p.sm2 = false;
+            if (!p.sm2) { p.GI = 1; p.TH = 0; p.NS = 1; }   // the halo plan below starts from scratch
+        }
+    }
+    if (p.flat || p.sm2) {
     } else if (p.smallic) {
         // stem layout: K = (kh) x [kw 0..7][ic 0..3]; the whole (tiny) channel depth is one stage
         p.NCH = 1;
@@ -429,6 +465,13 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     const bool x8 = x->n_bits == 8;
     if (p.flat) {
         launch_mfma_flat(a, p.cfg, p.niw, p.NS, p.wraw, p.s2, (unsigned)blocks, p.lds, s);
+        QE_LAUNCH_CHECK();
+        return QE_OK;
+    }
+    if (p.sm2) {
+        const int units = p.GI * p.IHT * ((sh->W + 3) / 4);
+        const int split = units <= 64 ? 4 : (units <= 128 ? 2 : 1);   // channel slices of the staging threads
+        launch_mfma_sm2(a, p.cfg == 0 ? 2 : 1, split, (unsigned)blocks, p.lds, s);
         QE_LAUNCH_CHECK();
         return QE_OK;
     }

@@ -1,0 +1,29 @@
+// qe_conv_mfma_i6.hip -- instantiations of the two-strips-per-wave 3x3 MFMA kernel.
+#include "qe_conv_mfma_kernel.hpp"
+
+namespace qe {
+
+template <int WMS, int SPLIT>
+static void launch_one(const MfmaArgs &a, unsigned blocks, size_t lds, hipStream_t s)
+{
+    // more than 64 KB of dynamic LDS needs the attribute once per kernel
+    static const bool raised = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_sm2_kernel<WMS, 9, SPLIT>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, MF_MAX_LDS_SM2) == hipSuccess;
+    (void)raised;
+    hipLaunchKernelGGL((conv_mfma_sm2_kernel<WMS, 9, SPLIT>), dim3(blocks), dim3(MF_THREADS), lds, s, a);
+}
+
+void launch_mfma_sm2(const MfmaArgs &a, int wms, int split, unsigned blocks, size_t lds, hipStream_t s)
+{
+    if (wms == 2) {
+        if (split == 4) launch_one<2, 4>(a, blocks, lds, s);
+        else if (split == 2) launch_one<2, 2>(a, blocks, lds, s);
+        else launch_one<2, 1>(a, blocks, lds, s);
+    } else {
+        if (split == 4) launch_one<1, 4>(a, blocks, lds, s);
+        else if (split == 2) launch_one<1, 2>(a, blocks, lds, s);
+        else launch_one<1, 1>(a, blocks, lds, s);
+    }
+}
+
+}  // namespace qe

@@ -16,6 +16,7 @@ constexpr int MF_THREADS = 256;
 constexpr int MF_UNITS = 2;        // staging units (16 ch x 4 px) per thread per chunk
 constexpr int MF_TRASH = 64;       // per-lane LDS slots that swallow masked-off staging writes
 constexpr int MF_MAX_LDS = 64 * 1024;
+constexpr int MF_MAX_LDS_SM2 = 80 * 1024;   // sm2 kernel: 2 workgroups per CU x 80 KB = the CU's 160 KB
 
 struct MfmaArgs {
     const uint8_t *x;
@@ -503,6 +504,278 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs
     mfma_epilogue<WM, WN, NIW>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK);
 #ifdef QE_STAMP
     QE_ST(7);       // epilogue stores issued
+    if (a.dbg != nullptr && lane == 0) {
+        unsigned long long *o = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 10;
+        for (int i = 0; i < 8; ++i) o[i] = st[i];
+        o[8] = tprev - tstart;
+        o[9] = tstart;
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 kernel with TWO 32-row strips per wave and the weights in LDS ("sm2"), 8-bit activations.
+// Why: in the halo kernel's 4x1 layout every wave reads all 7 activation fragments of a tap from
+// LDS for 7 MFMAs: 4 waves x 7 KB per 224 MFMA cycles = 128 B/clk, the whole LDS bandwidth of the CU
+// before a single bank conflict (and the pixel-major halo image has ~50 % 2-way conflicts at row
+// breaks).  The matrix pipe therefore waited on ds_read (stamps: one MFMA per 58-68 cycles instead of 32).
+// Here a wave owns 2 strips x 4 column tiles: one activation fragment feeds 2 MFMAs, so the same
+// tile needs half the activation reads (4 waves x <= 4 KB per 256 MFMA cycles).  The price is that a
+// strip's weight fragment is now wanted by WN waves; they come from an LDS copy of the chunk's
+// weights (Wt order is already fragment order: straight 16-byte copies, conflict-free b128 reads)
+// that is prefetched global -> VGPR during the previous chunk's MFMA phase exactly like the
+// activations, so no wave ever waits for an L2 round trip inside the MFMA phase.
+// Wave layout: WMS strip pairs x WN = 4 / WMS waves along the pixels (WMS = 2: 128 oc x <= 8 column
+// tiles, WMS = 1: 64 oc x <= 16 column tiles); column tile of slot t = wn + t * WN.  A slot outside the
+// tile (7 column tiles split 4 + 3) computes on pixel 0 and is never stored: a wave-uniform branch around
+// it made hipcc spill 700-900 VGPRs (two live copies of the accumulators).
+// Tile geometry, LDS halo image, staging threads and epilogue are the halo kernel's.
+// ---------------------------------------------------------------------------------------------
+template <int WMS, int KKT, int SPLIT>
+__global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_sm2_kernel(const MfmaArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint4 *Xs = reinterpret_cast<uint4 *>(smem);
+
+    constexpr int MT = 64 * WMS;
+    constexpr int WN = 4 / WMS;
+    constexpr int NIW = 4;
+    constexpr int KW_T = 3;
+    constexpr int WPIECES = KKT * 2 * MT;                          // 16-byte weight pieces per chunk
+    constexpr int PW = (WPIECES + MF_THREADS - 1) / MF_THREADS;    // per thread
+    constexpr int SEG_PER_I = MF_THREADS / MT;                     // (tap, half) segments covered per piece round
+    constexpr int TPS = MF_THREADS / SPLIT;                        // staging threads per channel slice
+    constexpr int CPT = 32 / SPLIT;                                // channels a staging thread fetches per chunk
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wms = wave % WMS, wn = wave / WMS;
+    const int col = lane & 31, h = lane >> 5;
+
+    int pt, ot, th;
+    TileGeom g;
+    if (!decode_tile(a, pt, ot, g, th)) return;
+    const int NT = g.NT;
+    const int ih0 = g.oh0 * a.stride - a.pad;
+    const int ISZ = a.IHT * a.IWP;
+    const int GSZ = a.GI * ISZ;
+    constexpr int KK = KKT;
+    const int trash = 2 * GSZ + lane;
+    int *sxp = reinterpret_cast<int *>(Xs + 2 * GSZ + MF_TRASH);
+    uint4 *Ws = reinterpret_cast<uint4 *>(smem + ((((2 * GSZ + MF_TRASH) * 16 + GSZ * 4) + 15) & ~15));   // [KKT*2][MT] (+ slack to PW * 256 pieces)
+
+    for (int i = tid; i < 2 * GSZ; i += MF_THREADS) Xs[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < GSZ; i += MF_THREADS) sxp[i] = 0;
+
+    const int RS = a.stride, CS = a.stride;
+    int pixidx[NIW];
+#pragma unroll
+    for (int t = 0; t < NIW; ++t) {
+        const int q = (wn + t * WN) * 32 + col;
+        const int gi = (a.GI > 1) ? q / g.OHWt : 0;
+        const int rq = q - gi * g.OHWt;
+        const int r = rq / a.OW, c = rq - r * a.OW;
+        pixidx[t] = h * GSZ + ((q < NT) ? gi * ISZ + (r * RS) * a.IWP + c * CS : 0);
+    }
+
+    // ---- activation staging: thread <-> (channel slice, image gi, halo row l, column quad iq).  A tile has
+    // only 60-90 (row, quad) units, so one wave used to do all the fetching, transposing and LDS writing of
+    // a chunk while three waited at the barrier; SPLIT slices of 32 / SPLIT channels spread it over all four.
+    const int NQ = (a.W + 3) >> 2;
+    const int HW = a.H * a.W;
+    const int64_t img_off = (int64_t)g.n0 * a.IC * HW;
+    const int slice = __builtin_amdgcn_readfirstlane(tid / TPS);
+    int u_off, u_sh = 0, u_lds[4];
+    {
+        const int lt = tid - slice * TPS;
+        const int gi = lt / (a.IHT * NQ);
+        const int rr = lt - gi * (a.IHT * NQ);
+        const int l = rr / NQ, iq = rr - l * NQ;
+        const int ih = ih0 + l;
+        const bool ok = gi < a.GI && g.n0 + gi < a.N && ih >= 0 && ih < a.H;
+        int iw0 = 4 * iq;
+        if (iw0 + 4 > a.W) { u_sh = 8 * (iw0 + 4 - a.W); iw0 = a.W - 4; }
+        u_off = ok ? gi * a.IC * HW + ih * a.W + iw0 : 0;
+        if (!ok) u_sh = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int iw = 4 * iq + j;
+            const int cl = iw + a.pad;
+            const bool pok = ok && iw < a.W && cl < a.IWP;
+            u_lds[j] = pok ? (gi * a.IHT + l) * a.IWP + cl : -1;
+        }
+    }
+    const uint8_t *xi = a.x + img_off;
+
+    // ---- weight staging: piece e = tid + 256 i <-> segment (tap, half) = e / MT, row e % MT of Wt ----
+    const int seg0 = tid / MT, within = tid - seg0 * MT;
+    const int tap0 = seg0 >> 1, hh0 = seg0 & 1;
+    constexpr int TAP_PER_I = SEG_PER_I / 2;                       // taps advanced per piece round (1 or 2)
+    const int64_t grp_stride = (int64_t)a.OCP * 16;
+    const int64_t tap_stride = (int64_t)a.NG * grp_stride;
+    const int8_t *w_thr = a.wt + ((int64_t)hh0 * a.OCP + ot * MT + within) * 16;   // + tap * tap_stride + 2s * grp_stride
+
+    int zw_local = 0;
+    if (tid < MT) zw_local = (a.ep[a.OCP + ot * MT + tid] != 0.0f) ? 1 : 0;
+    const bool need_sx = __syncthreads_or(zw_local) != 0;
+
+#ifdef QE_STAMP
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = qe_stamp();
+    const unsigned long long tstart = tprev;
+#endif
+    uint32_t d[CPT];
+    // weights of chunk s: LDS-DMA (global_load_lds_dwordx4), 16-byte pieces straight into Ws with no VGPR
+    // round trip (a register-staged prefetch needs 36 more VGPRs than this kernel has: hipcc then keeps the
+    // staging array in scratch and serialises the loads).  Lane l of a wave lands at base + 16 l, which is
+    // exactly the piece order of Ws.  Rounds past the last tap (MT = 64) re-read tap 8 into the slack rows.
+    auto issue_w = [&](int s) __attribute__((always_inline)) {
+        const int8_t *ws = w_thr + (int64_t)(2 * s) * grp_stride;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int tap = tap0 + i * TAP_PER_I;
+            const int tapc = tap < KKT ? tap : KKT - 1;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(ws + (int64_t)tapc * tap_stride),
+                (__attribute__((address_space(3))) void *)(Ws + MF_THREADS * i + 64 * wave), 16, 0, 0);
+        }
+    };
+    auto issue_x = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int ic = s * 32 + slice * CPT + i;               // wave-uniform
+            const int icc = ic < a.IC ? ic : a.IC - 1;
+            const uint8_t *plane = xi + (int64_t)icc * HW;
+            uint32_t v;
+            __builtin_memcpy(&v, plane + (uint32_t)u_off, 4);
+            d[i] = v;
+        }
+    };
+    auto stage_x = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) d[i] = (d[i] >> u_sh) ^ 0x80808080u;
+        uint32_t o[4][CPT / 4];
+#pragma unroll
+        for (int m = 0; m < CPT / 4; ++m)
+            transpose4x4(d[4 * m], d[4 * m + 1], d[4 * m + 2], d[4 * m + 3], o[0][m], o[1][m], o[2][m], o[3][m]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // pixel j: channels [slice * CPT, +CPT) of the chunk = bytes of the [pixel][16 ch] vector(s)
+            if constexpr (CPT == 32) {
+                const int idx = u_lds[j] >= 0 ? u_lds[j] : trash;
+                Xs[idx] = make_uint4(o[j][0], o[j][1], o[j][2], o[j][3]);
+                Xs[u_lds[j] >= 0 ? idx + GSZ : trash] = make_uint4(o[j][4], o[j][5], o[j][6], o[j][7]);
+            } else if constexpr (CPT == 16) {
+                const int idx = u_lds[j] >= 0 ? u_lds[j] + slice * GSZ : trash;
+                Xs[idx] = make_uint4(o[j][0], o[j][1], o[j][2], o[j][3]);
+            } else {
+                const int idx = u_lds[j] >= 0 ? u_lds[j] + (slice >> 1) * GSZ : trash;
+                *reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(&Xs[idx]) + (slice & 1) * 8) = make_uint2(o[j][0], o[j][1]);
+            }
+        }
+        if (need_sx) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int sum = 0;
+#pragma unroll
+                for (int m = 0; m < CPT / 4; ++m) {
+                    const int nv = a.IC - (s * 32 + slice * CPT + 4 * m);
+                    const int ones = nv >= 4 ? 0x01010101 : (nv <= 0 ? 0 : (0x01010101 & ((1 << (8 * nv)) - 1)));
+                    sum = __builtin_amdgcn_sdot4((int)o[j][m], ones, sum, false);
+                }
+                if (u_lds[j] >= 0) atomicAdd(&sxp[u_lds[j]], sum);
+            }
+        }
+    };
+    const uint4 *Wf = Ws + h * MT + (2 * wms) * 32 + col;    // + tap * 2 * MT (+ 32 for the second strip)
+    // A slot outside the tile (7 column tiles split 4 + 3) computes on pixel 0 and is never stored.  Skipping it
+    // was tried twice: a wave-uniform branch around it inside the chunk loop made hipcc keep two copies of the
+    // accumulators (700-900 spilled VGPRs); two whole instances of the loop + epilogue selected once per wave
+    // compiled cleanly but ran slower (56x56: 0.070 -> 0.091 ms, others unchanged).
+    constexpr int NTC = NIW;
+    v16i acc0[NIW], acc1[NIW];
+#pragma unroll
+    for (int t = 0; t < NIW; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[t][r] = 0; acc1[t][r] = 0; }
+    }
+    auto mma_chunk = [&]() __attribute__((always_inline)) {
+        // fragments of tap k+1 are requested before the MFMAs of tap k (one tap of lookahead, 24 VGPRs)
+        v4i af0, af1, b[NTC];
+        auto fetch = [&](int tap, v4i &f0, v4i &f1, v4i (&bb)[NTC]) __attribute__((always_inline)) {
+            const int off = (tap / KW_T) * a.IWP + (tap % KW_T);
+            const uint4 w0 = Wf[tap * 2 * MT], w1 = Wf[tap * 2 * MT + 32];
+            f0 = v4i{(int)w0.x, (int)w0.y, (int)w0.z, (int)w0.w};
+            f1 = v4i{(int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w};
+#pragma unroll
+            for (int t = 0; t < NTC; ++t) bb[t] = *reinterpret_cast<const v4i *>(&Xs[pixidx[t] + off]);
+        };
+        fetch(0, af0, af1, b);
+#pragma unroll
+        for (int tap = 0; tap < KKT; ++tap) {
+            v4i nf0 = af0, nf1 = af1, nb[NTC];
+#pragma unroll
+            for (int t = 0; t < NTC; ++t) nb[t] = b[t];
+            if (tap + 1 < KKT) fetch(tap + 1, nf0, nf1, nb);
+#pragma unroll
+            for (int t = 0; t < NTC; ++t) {
+                acc0[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af0, b[t], acc0[t], 0, 0, 0);
+                acc1[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af1, b[t], acc1[t], 0, 0, 0);
+            }
+            af0 = nf0; af1 = nf1;
+#pragma unroll
+            for (int t = 0; t < NTC; ++t) b[t] = nb[t];
+            // issue order inside the tap: one fragment read of tap k+1 ahead of each of the first MFMAs of
+            // tap k (left alone, hipcc sinks all six reads behind the seventh MFMA: 32 cycles of lookahead)
+#pragma unroll
+            for (int j = 0; j < NTC + 2; ++j) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NTC - (NTC + 2), 0);
+            __builtin_amdgcn_sched_barrier(0);   // keep later taps' fragment reads from piling up in registers
+        }
+    };
+    // per chunk: X(s) registers -> LDS, W(s) landed -> barrier -> request X(s+1) -> MFMA -> barrier -> request W(s+1)
+    // (single weight buffer: its refill has to wait for the last reader, and lands while the next stage_x runs)
+    auto stage = [&](int s, auto prefetch) __attribute__((always_inline)) {
+        stage_x(s);
+        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the LDS-DMA of W(s) has landed
+        QE_ST(1);   // wait X, W + transposes + LDS writes
+        __syncthreads();
+        QE_ST(2);   // barrier 1
+        if constexpr (decltype(prefetch)::value) issue_x(s + 1);
+        QE_ST(3);   // X(s+1) issue
+        mma_chunk();
+        QE_ST(4);   // MFMA phase
+        __syncthreads();
+        QE_ST(5);   // barrier 2
+        if constexpr (decltype(prefetch)::value) issue_w(s + 1);
+    };
+
+    issue_x(0);
+    issue_w(0);
+    QE_ST(0);
+    for (int s = 0; s < a.NCH - 1; ++s) stage(s, std::true_type{});
+    stage(a.NCH - 1, std::false_type{});
+
+    int sxs[NTC];
+#pragma unroll
+    for (int t = 0; t < NTC; ++t) {
+        sxs[t] = 0;
+        if (need_sx) {
+            const int pbase = pixidx[t] - h * GSZ;
+            for (int tap = 0; tap < KK; ++tap) {
+                const int kh = tap / a.KW;
+                sxs[t] += sxp[pbase + kh * a.IWP + (tap - kh * a.KW)];
+            }
+        }
+    }
+    QE_ST(6);
+    mfma_epilogue<2 * WMS, WN, NTC>(a, acc0, sxs, need_sx, g, ot, 2 * wms, wn, col, h, KK);
+    mfma_epilogue<2 * WMS, WN, NTC>(a, acc1, sxs, need_sx, g, ot, 2 * wms + 1, wn, col, h, KK);
+#ifdef QE_STAMP
+    QE_ST(7);
     if (a.dbg != nullptr && lane == 0) {
         unsigned long long *o = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 10;
         for (int i = 0; i < 8; ++i) o[i] = st[i];
@@ -1252,6 +1525,7 @@ void launch_mfma_cfg1(const MfmaArgs &a, int niw, int ns, int KK, bool x8, unsig
 void launch_mfma_cfg2(const MfmaArgs &a, int niw, int ns, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_smallic(const MfmaArgs &a, int cfg, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_ws(const MfmaArgs &a, int niw, int split, unsigned blocks, size_t lds, hipStream_t s);
+void launch_mfma_sm2(const MfmaArgs &a, int wms, int split, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_flat(const MfmaArgs &a, int cfg, int niw, int ns, bool wraw, bool s2, unsigned blocks, size_t lds, hipStream_t s);
 
 #define QE_MFMA_K(WM, WN, NIW, KKT, X8, NS) \

@@ -154,6 +154,9 @@ SWEEP_SHAPES = [
     (2, 160, 14, 14, 200, 1, 1, 0),  # multi-chunk stages with a padded last stage
     (2, 128, 56, 56, 160, 1, 2, 0),  # stride-2 1x1 on the flat kernel (OW = 28)
     (2, 96, 28, 28, 130, 1, 2, 0),   # stride-2 1x1, OW = 14 (byte-aligned LDS rows)
+    (3, 40, 9, 9, 48, 3, 1, 1),      # 3x3 two-strip kernel, 64-channel workgroups, several images per tile
+    (2, 70, 20, 20, 130, 3, 2, 1),   # 3x3 two-strip kernel, stride 2, partial oc tile, padded last chunk
+    (1, 64, 56, 56, 64, 3, 1, 1),    # 3x3 two-strip kernel, 14 column tiles over 4 pixel waves
 ]
 
 
@@ -245,17 +248,20 @@ def test_conv_error_messages(engine):
     assert tuple(y.shape) == (1, 6, 8, 8) and float(y.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("env", [{"QE_WS": "1"}, {"QE_WS": "1", "QE_WS_NOPAD": "1"}, {"QE_WS": "0"}, {"QE_FLAT_NIW": "4"}, {"QE_FLAT_NIW": "5"}, {"QE_FLAT_NIW": "7"}])
+@pytest.mark.parametrize("env", [{"QE_SM2": "0", "QE_WS": "1"}, {"QE_SM2": "0", "QE_WS": "1", "QE_WS_NOPAD": "1"},
+                                 {"QE_SM2": "0", "QE_WS": "0"}, {"QE_SM2": "1"}, {"QE_FLAT_NIW": "4"}, {"QE_FLAT_NIW": "5"},
+                                 {"QE_FLAT_NIW": "7"}, {"QE_CHUNK_IMAGES": "0"}, {"QE_CHUNK_IMAGES": "1"}])
 def test_kernel_variants_forced_by_env(engine, env):
-    """The tuning knobs select other kernel variants (warp-specialised 3x3 with padded / unpadded LDS rows,
-    single-role 3x3, 128-pixel flat tiles); every variant must meet the same parity bar."""
+    """The tuning knobs select other kernel variants (two-strip / warp-specialised (padded, unpadded LDS rows) /
+    single-role 3x3, flat tile widths, block maps); every variant must meet the same parity bar."""
     import os
     rng = np.random.RandomState(17)
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
         for shp in [(2, 256, 14, 14, 256, 3, 1, 1), (3, 128, 28, 28, 128, 3, 1, 1), (4, 160, 7, 7, 130, 3, 1, 1),
-                    (2, 128, 14, 14, 192, 3, 2, 1), (2, 256, 28, 28, 160, 1, 1, 0)]:
+                    (2, 128, 14, 14, 192, 3, 2, 1), (2, 256, 28, 28, 160, 1, 1, 0), (5, 64, 7, 7, 48, 3, 1, 1),
+                    (9, 96, 30, 30, 130, 3, 2, 1)]:
             for zeros in (False, True):
                 case = _random_case(rng, *shp, 8, 1, 8, 0 if zeros else 1, w_pc=True, a_pc=False, zeros=zeros, bias=True)
                 y, o32, o64 = _run_case(engine, case, via_capi=True)
