@@ -3,7 +3,6 @@
 import csv, glob, json, os, sys
 out, tag = sys.argv[1], sys.argv[2]
 os.makedirs("profiles", exist_ok=True)
-steps = 7  # --steps 5 --warmup 2
 # kernel stats
 f = glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True)
 if f:
@@ -20,6 +19,7 @@ if f:
     tot_conv = sum(float(r["TotalDurationNs"]) for r in conv)
     calls_conv = sum(int(r["Calls"]) for r in conv)
     tot_prep = sum(float(r["TotalDurationNs"]) for r in prep)
+    steps = calls_conv / 53.0   # 53 conv launches per step (timed + warm-up steps)
     print("conv kernels: %d launches, %.3f ms per step, avg %.1f us per launch; prep: %.3f ms per step" % (
         calls_conv, tot_conv / steps / 1e6, tot_conv / calls_conv / 1e3, tot_prep / steps / 1e6))
 def pmc_sum(kind, counter):
