@@ -146,6 +146,28 @@ int qe_quantconv2d_float_input(const float *x, const qe_qparam *w, const float *
  * and profiles): 0 = generic fp32 direct convolution, 1 = int8 MFMA implicit GEMM. */
 int qe_quantconv2d_path(const qe_conv_shape *shape, const qe_qparam *x, const qe_qparam *w);
 
+/* ---- quantlinear ------------------------------------------------------------
+ * Replaces quantlinear / quantlinear_cuda (functions/quantlinear.cu:233-297, :153-214):
+ *   out[b, o] = bias[o] + sum_k (q_x[b,k] + zx[b]) * (q_w[o,k] + zw[o]) * (sx[b] * sw[o])
+ * Both operands are packed b-bit streams (x: B*K elements, row major; w: O*K elements, OIHW of a Linear).
+ * NOTE the conventions of THIS reference kernel (they differ from quantconv2d): the zero point is ADDED
+ * (quantlinear.cu:115,120) and the activation scale/zero are indexed by the batch ROW (:96-99).
+ * x->n_param is 1 (broadcast: the reference expands 0-dim tensors, :276-282) or B; w->n_param is 1 or O.
+ * bias may be NULL (the reference substitutes zeros, :268).  out: B*O floats, fully written.
+ * The reference accumulates stale shared memory when K % 32 != 0 (:76-92 never zero-fills the tail);
+ * this entry point computes the sum over k < K for every K.                                            */
+int qe_quantlinear(const qe_qparam *x, const qe_qparam *w, const float *bias,
+                   int64_t B, int32_t K, int32_t O, float *out, qe_stream_t stream);
+
+/* Replaces quantlinear_float_input (functions/quantlinear_float_input.cu:120-182, kernel :36-104):
+ *   out[b, o] = bias[o] + sum_k x[b,k] * ((q_w[o,k] - zw[o]) * sw[o])      ((q - zero): :82-86)
+ * x: B*K floats.  w->n_param is 1 (per tensor iff numel()==1, :170) or O.                              */
+int qe_quantlinear_float_input(const float *x, const qe_qparam *w, const float *bias,
+                               int64_t B, int32_t K, int32_t O, float *out, qe_stream_t stream);
+
+/* 0 = order-preserving fp32 kernel, 1 = int8 MFMA GEMM (8-bit x 8-bit operands, K % 64 == 0, 16-byte aligned streams). */
+int qe_quantlinear_path(const qe_qparam *x, const qe_qparam *w, int64_t B, int32_t K, int32_t O);
+
 #ifdef __cplusplus
 }
 #endif

@@ -338,10 +338,155 @@ def gen_g4():
     np.savez_compressed(os.path.join(OUT, "g4_module.npz"), **out)
 
 
+# --------------------------------------------------------------------------------------
+# G5: quantlinear / quantlinear_float_input cases.  Packed operands from the REFERENCE packer; expected values are
+#   (a) the reference module's own packed-forward arithmetic (quantlinear.py:158-161):
+#       F.linear((q_x + z_x) * s_x, (q_w + z_w) * s_w, bias) in fp32,
+#   (b) the same in float64 (torch), independent of the C oracle,
+#   (c) the C oracle's fp32 chains (for the tolerance bookkeeping of the GPU tests).
+# Zeros are stored in the convention of the kernel they are passed to: quantlinear takes (q + zero)
+# (quantlinear.cu:115,120), quantlinear_float_input takes (q - zero) (quantlinear_float_input.cu:82-86).
+G5_SHAPES = [(1, 1, 1), (3, 5, 2), (7, 32, 9), (4, 37, 33), (33, 64, 65), (16, 160, 40), (5, 768, 24)]
+G5_QUANT = [(8, 1, 8, 1), (8, 0, 8, 0), (4, 1, 4, 1), (3, 1, 6, 0), (8, 1, 0, 0), (5, 0, 0, 0)]
+
+
+def gen_g5():
+    rng = np.random.RandomState(2468)
+    out, index = {}, []
+    case = 0
+    for (B, K, O) in G5_SHAPES:
+        for (wb, wsgn, ab, asgn) in G5_QUANT:
+            w_per_channel = (case % 2) == 0
+            a_per_row = ab != 0 and (case % 3) == 1
+            nonzero_zero = (case % 4) in (1, 2)
+            with_bias = (case % 2) == 1
+            case += 1
+            wlo, whi = qrange(wb, wsgn)
+            qw = rng.randint(wlo, whi + 1, size=(O, K)).astype(np.int32)
+            n_ws = O if w_per_channel else 1
+            sw = rng.uniform(2.5e-4, 7.5e-4, size=n_ws).astype(np.float32)
+            zw = (rng.uniform(-3.0, 3.0, size=n_ws).astype(np.float32) if nonzero_zero else np.zeros(n_ws, np.float32))
+            w_packed, w_des = ref_pack(qw, wb, wsgn)
+            bias = rng.normal(0, 0.1, size=O).astype(np.float32) if with_bias else None
+            key = "l%03d" % len(index)
+            b_t = None if bias is None else torch.from_numpy(bias)
+            qw64 = torch.from_numpy(qw.astype(np.float64))
+            sw64 = torch.from_numpy(sw).double().view(-1, 1)
+            zw64 = torch.from_numpy(zw).double().view(-1, 1)
+            if ab == 0:
+                x = rng.normal(0, 1, size=(B, K)).astype(np.float32)
+                out[key + "_x"] = x
+                wf64 = (qw64 - zw64) * sw64                            # (q - zero) * scale
+                exact64 = F.linear(torch.from_numpy(x).double(), wf64, None if bias is None else b_t.double()).numpy()
+                ref_f = F.linear(torch.from_numpy(x), wf64.float(), b_t).numpy()
+                chain = oracle.quantlinear_float_input(x, w_packed, w_des, sw, zw, bias, mode="fp32")
+                chain_fma = oracle.quantlinear_float_input(x, w_packed, w_des, sw, zw, bias, mode="fp32_fma")
+            else:
+                alo, ahi = qrange(ab, asgn)
+                qx = rng.randint(alo, ahi + 1, size=(B, K)).astype(np.int32)
+                n_as = B if a_per_row else 1
+                sx = (rng.uniform(1e-3, 3e-3, size=n_as).astype(np.float32) if a_per_row else np.array([2e-3], np.float32))
+                zx = (rng.uniform(-5.0, 5.0, size=n_as).astype(np.float32) if nonzero_zero else np.zeros(n_as, np.float32))
+                x_packed, x_des = ref_pack(qx, ab, asgn)
+                out[key + "_x_packed"] = x_packed
+                out[key + "_x_des"] = x_des
+                out[key + "_x_scale"] = sx
+                out[key + "_x_zero"] = zx
+                xf64 = (torch.from_numpy(qx.astype(np.float64)) + torch.from_numpy(zx).double().view(-1, 1)) * \
+                    torch.from_numpy(sx).double().view(-1, 1)          # (q + zero) * scale, per ROW
+                wf64 = (qw64 + zw64) * sw64
+                exact64 = F.linear(xf64, wf64, None if bias is None else b_t.double()).numpy()
+                ref_f = F.linear(xf64.float(), wf64.float(), b_t).numpy()   # quantlinear.py:158-161
+                chain = oracle.quantlinear(x_packed, x_des, sx, zx, w_packed, w_des, sw, zw, bias, mode="fp32")
+                chain_fma = oracle.quantlinear(x_packed, x_des, sx, zx, w_packed, w_des, sw, zw, bias, mode="fp32_fma")
+            out[key + "_w_packed"] = w_packed
+            out[key + "_w_des"] = w_des
+            out[key + "_w_scale"] = sw
+            out[key + "_w_zero"] = zw
+            if bias is not None:
+                out[key + "_bias"] = bias
+            out[key + "_ref_flinear"] = ref_f
+            out[key + "_exact64"] = exact64
+            out[key + "_chain32"] = chain
+            out[key + "_chain32_fma"] = chain_fma
+            out[key + "_meta"] = np.array([B, K, O, wb, wsgn, ab, asgn], np.int32)
+            index.append(key)
+    out["index"] = np.array(index)
+    np.savez_compressed(os.path.join(OUT, "g5_linear.npz"), **out)
+    print("G5: %d cases" % len(index))
+
+
+def gen_g6():
+    """Module capture: the reference's QuantLinear (modelzoo/modules/quantlinear.py) calibrated, packed
+    (:123-148 -> tpack), reloaded (:166-186 -> tunpack) and run through its packed forward (:150-161)."""
+    mm = import_ref_modules()
+    out, index = {}, []
+    torch.manual_seed(11)
+    cfgs = [
+        ("w8a8_sym", 48, 20,
+         dict(n_bits=8, symmetric=True, signed=True, granularity="channel", range={"name": "minmax"}),
+         dict(n_bits=8, symmetric=True, signed=True, granularity="layer", range={"name": "minmax"})),
+        ("w8a8_asym", 40, 24,
+         dict(n_bits=8, symmetric=False, signed=False, granularity="channel", range={"name": "minmax"}),
+         dict(n_bits=8, symmetric=False, signed=False, granularity="layer", range={"name": "minmax"})),
+        ("w4_layer_a8", 64, 10,
+         dict(n_bits=4, symmetric=True, signed=True, granularity="layer", range={"name": "minmax"}),
+         dict(n_bits=8, symmetric=True, signed=True, granularity="layer", range={"name": "minmax"})),
+    ]
+    for (name, fin, fout, w_set, a_set) in cfgs:
+        lin = torch.nn.Linear(fin, fout, bias=True)
+        x = torch.randn(12, fin)
+        x = torch.relu(x) if not a_set["symmetric"] else x
+
+        def make():
+            return mm.QuantLinear(fin, fout, w_setting=w_set, a_setting=a_set,
+                                  _parameters={"weight": lin.weight.detach().clone(), "bias": lin.bias.detach().clone()})
+
+        m = make()
+        with torch.no_grad():
+            m.calibrating = True
+            m(x)
+            m.calibrating = False
+            for mod in m.modules():
+                if isinstance(mod, mm.Quantizer):
+                    mod.quant(True)
+            y_sim = m(x)
+            m.pack()
+            sd = {kk: vv.clone() for kk, vv in m.state_dict().items()}
+            m2 = make()
+            m2.load_state_dict(sd)
+            for mod in m2.modules():
+                if isinstance(mod, mm.Quantizer):
+                    mod.quant(True)
+            y_packed = m2(x)
+            qx, a_scale, a_zero = m2.a_quantizer(x)
+        key = "m_" + name
+        out[key + "_x"] = x.numpy()
+        out[key + "_qx"] = qx.numpy()
+        out[key + "_a_scale"] = a_scale.numpy().reshape(-1)
+        out[key + "_a_zero_py"] = a_zero.numpy().reshape(-1)    # PYTHON convention (q + zero) * scale
+        out[key + "_a_bits_sign"] = np.array([a_set["n_bits"], int(qx.min() < 0)], np.int32)
+        out[key + "_weight_packed"] = sd["weight"].numpy()
+        out[key + "_w_des"] = sd["w_des"].numpy()
+        out[key + "_w_scale"] = sd["w_scale"].numpy()
+        out[key + "_w_zero_py"] = sd["w_zero"].numpy()
+        out[key + "_bias"] = sd["bias"].numpy()
+        out[key + "_y_sim"] = y_sim.numpy()
+        out[key + "_y_packed"] = y_packed.numpy()
+        index.append(key)
+        print("G6 %s: max|sim-packed| = %.3g, w_des=%s, w_scale shape %s, a_scale shape %s" % (
+            name, float((y_sim - y_packed).abs().max()), sd["w_des"].tolist(), tuple(sd["w_scale"].shape),
+            tuple(a_scale.shape)))
+    out["index"] = np.array(index)
+    np.savez_compressed(os.path.join(OUT, "g6_linear_module.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gen_g1()
     gen_g3()
     gen_g4()
+    gen_g5()
+    gen_g6()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -263,6 +263,106 @@ int qe_oracle_quantconv2d_float_input(
     return QE_ORACLE_OK;
 }
 
+/* ------------------------------------------------------------------------- */
+/* quantlinear: engine/kernels/functions/quantlinear.cu:39-133 (one output     */
+/* element per thread, 32-wide K tiles) restated as the per-element sum.       */
+/* NOTE the conventions of THIS kernel, which differ from the conv kernels:    */
+/*   * (q + zero): input_value = q_x + input_zero[row]   (:113-115)            */
+/*                 weight_value = q_w + weight_zero[col] (:118-120)            */
+/*   * the input scale/zero are indexed by the batch ROW, the weight's by the  */
+/*     output COLUMN; s_scale = input_scale[row] * weight_scale[col] is one    */
+/*     fp32 product (:96) applied inside the loop: tmp += x * w * s (:123)     */
+/*   * tmp starts at 0 and the bias is added last (:131)                       */
+/* x_per_tensor / w_per_tensor: the host expands 0-dim scales (:276-290); this */
+/* restatement broadcasts element 0 instead.                                   */
+/* The reference reads stale shared memory for K % 32 != 0 (no zero fill,      */
+/* :76-92); the restatement is the mathematically intended sum over k < K.     */
+/* modes as in qe_oracle_quantconv2d.                                          */
+/* ------------------------------------------------------------------------- */
+int qe_oracle_quantlinear(
+    const uint8_t *x, int x_bits, int x_sign,
+    const float *x_scale, const float *x_zero, int x_per_tensor,
+    const uint8_t *w, int w_bits, int w_sign,
+    const float *w_scale, const float *w_zero, int w_per_tensor,
+    const float *bias, /* may be NULL (host substitutes zeros, :268) */
+    int B, int K, int O, int mode, float *out, double *out_f64)
+{
+    const int64_t total = (int64_t)B * O;
+#pragma omp parallel for schedule(static)
+    for (int64_t index = 0; index < total; index++) {
+        const int row = (int)(index / O), col = (int)(index % O);
+        const float zx = x_per_tensor ? x_zero[0] : x_zero[row];
+        const float zw = w_per_tensor ? w_zero[0] : w_zero[col];
+        const float sx = x_per_tensor ? x_scale[0] : x_scale[row];
+        const float sw = w_per_tensor ? w_scale[0] : w_scale[col];
+        const float s = sx * sw;                                   /* :96 */
+        float tmp = 0.0f;                                          /* :70 */
+        double tmp64 = 0.0;
+        for (int k = 0; k < K; k++) {
+            int qx = qe_unpack_elem(x, (int64_t)row * K + k, x_bits, x_sign);   /* :78-83 */
+            int qw = qe_unpack_elem(w, (int64_t)col * K + k, w_bits, w_sign);   /* :87-92 */
+            if (mode == 2) {
+                tmp64 += ((double)qx + (double)zx) * ((double)qw + (double)zw) * ((double)sx * (double)sw);
+            } else {
+                float iv = (float)qx + zx;                         /* :115 */
+                float wv = (float)qw + zw;                         /* :120 */
+                if (mode == 1) tmp = fmaf(iv * wv, s, tmp);
+                else           tmp += iv * wv * s;                 /* :123 */
+            }
+        }
+        if (mode == 2) {
+            double v = tmp64 + (bias ? (double)bias[col] : 0.0);
+            out[index] = (float)v;
+            if (out_f64) out_f64[index] = v;
+        } else {
+            out[index] = tmp + (bias ? bias[col] : 0.0f);          /* :131 */
+        }
+    }
+    return QE_ORACLE_OK;
+}
+
+/* ------------------------------------------------------------------------- */
+/* quantlinear_float_input: functions/quantlinear_float_input.cu:36-104.      */
+/* (q - zero) * scale convention for the weight (:82-86), fp32 input, sum from */
+/* 0 and the bias added last (:102).  Same K-tail remark and modes as above.   */
+/* ------------------------------------------------------------------------- */
+int qe_oracle_quantlinear_float_input(
+    const float *x,
+    const uint8_t *w, int w_bits, int w_sign,
+    const float *w_scale, const float *w_zero, int w_per_tensor,
+    const float *bias,
+    int B, int K, int O, int mode, float *out, double *out_f64)
+{
+    const int64_t total = (int64_t)B * O;
+#pragma omp parallel for schedule(static)
+    for (int64_t index = 0; index < total; index++) {
+        const int row = (int)(index / O), col = (int)(index % O);
+        const float zw = w_per_tensor ? w_zero[0] : w_zero[col];
+        const float sw = w_per_tensor ? w_scale[0] : w_scale[col];
+        float acc = 0.0f;                                          /* :62 */
+        double acc64 = 0.0;
+        for (int k = 0; k < K; k++) {
+            int qw = qe_unpack_elem(w, (int64_t)col * K + k, w_bits, w_sign);   /* :73-77 */
+            float xf = x[(int64_t)row * K + k];                    /* :68 */
+            if (mode == 2) {
+                acc64 += (double)xf * (((double)qw - (double)zw) * (double)sw);
+            } else {
+                float wf = ((float)qw - zw) * sw;                  /* :82-86 */
+                if (mode == 1) acc = fmaf(xf, wf, acc);
+                else           acc += xf * wf;                     /* :95 */
+            }
+        }
+        if (mode == 2) {
+            double v = acc64 + (bias ? (double)bias[col] : 0.0);
+            out[index] = (float)v;
+            if (out_f64) out_f64[index] = v;
+        } else {
+            out[index] = acc + (bias ? bias[col] : 0.0f);          /* :102 */
+        }
+    }
+    return QE_ORACLE_OK;
+}
+
 /* Number of OpenMP threads the conv loops will use (for bench.py's `cores`). */
 #ifdef _OPENMP
 #include <omp.h>

@@ -58,6 +58,12 @@ def _load():
     lib.qe_oracle_quantconv2d_float_input.argtypes = (
         [f32p, u8p, i32, i32, f32p, f32p, i32, f32p] + [i32] * 9 + [i32, f32p, f64p])
     lib.qe_oracle_quantconv2d_float_input.restype = i32
+    lib.qe_oracle_quantlinear.argtypes = (
+        [u8p, i32, i32, f32p, f32p, i32, u8p, i32, i32, f32p, f32p, i32, f32p] + [i32] * 3 + [i32, f32p, f64p])
+    lib.qe_oracle_quantlinear.restype = i32
+    lib.qe_oracle_quantlinear_float_input.argtypes = (
+        [f32p, u8p, i32, i32, f32p, f32p, i32, f32p] + [i32] * 3 + [i32, f32p, f64p])
+    lib.qe_oracle_quantlinear_float_input.restype = i32
     lib.qe_oracle_num_threads.restype = i32
     lib.qe_oracle_set_num_threads.argtypes = [i32]
     _lib = lib
@@ -179,4 +185,49 @@ def quantconv2d_float_input(x, w, w_des, w_scale, w_zero, bias, stride, padding,
         _ptr(sw, ctypes.c_float), _ptr(zw, ctypes.c_float), 1 if sw.size == 1 else 0,
         _ptr(b, ctypes.c_float), N, IC, H, W, OC, KH, KW, int(stride), int(padding),
         MODES[mode], _ptr(out, ctypes.c_float), _ptr(out64, ctypes.c_double)))
+    return (out, out64) if return_f64 else out
+
+
+def quantlinear(x, x_des, x_scale, x_zero, w, w_des, w_scale, w_zero, bias, mode="fp32", return_f64=False):
+    """reference: quantlinear(...) 9 positional args (functions/quantlinear.cu:233-243).
+    KERNEL convention of this op: (q + zero), input scale/zero per batch ROW, weight's per output COLUMN."""
+    lib = _load()
+    x = np.ascontiguousarray(x, dtype=np.uint8).reshape(-1)
+    w = np.ascontiguousarray(w, dtype=np.uint8).reshape(-1)
+    x_des, w_des = np.asarray(x_des), np.asarray(w_des)
+    xb, xs = int(x_des[0]), int(x_des[1])
+    B, K = int(x_des[2]), int(x_des[3])               # quantlinear.cu:255,272-273
+    wb, ws = int(w_des[0]), int(w_des[1])
+    O, K2 = int(w_des[2]), int(w_des[3])              # :258,274
+    if K != K2:
+        raise OracleError("Input and weight do not match")   # :259
+    sx, zx, sw, zw = _f32(x_scale), _f32(x_zero), _f32(w_scale), _f32(w_zero)
+    b = None if bias is None else _f32(bias)
+    out = np.zeros((B, O), dtype=np.float32)
+    out64 = np.zeros(out.shape, dtype=np.float64) if return_f64 else None
+    _check(lib.qe_oracle_quantlinear(
+        _ptr(x, ctypes.c_uint8), xb, xs, _ptr(sx, ctypes.c_float), _ptr(zx, ctypes.c_float), 1 if sx.size == 1 else 0,
+        _ptr(w, ctypes.c_uint8), wb, ws, _ptr(sw, ctypes.c_float), _ptr(zw, ctypes.c_float), 1 if sw.size == 1 else 0,
+        _ptr(b, ctypes.c_float), B, K, O, MODES[mode], _ptr(out, ctypes.c_float), _ptr(out64, ctypes.c_double)))
+    return (out, out64) if return_f64 else out
+
+
+def quantlinear_float_input(x, w, w_des, w_scale, w_zero, bias, mode="fp32", return_f64=False):
+    """reference: quantlinear_float_input(...) 6 positional args (functions/quantlinear_float_input.cu:120-126).
+    (q - zero) * scale convention for the weight."""
+    lib = _load()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    B, K = x.shape
+    w = np.ascontiguousarray(w, dtype=np.uint8).reshape(-1)
+    w_des = np.asarray(w_des)
+    wb, ws = int(w_des[0]), int(w_des[1])
+    O = int(w_des[2])                                 # :150 (weight_shape[1] is never compared with K)
+    sw, zw = _f32(w_scale), _f32(w_zero)
+    b = None if bias is None else _f32(bias)
+    out = np.zeros((B, O), dtype=np.float32)
+    out64 = np.zeros(out.shape, dtype=np.float64) if return_f64 else None
+    _check(lib.qe_oracle_quantlinear_float_input(
+        _ptr(x, ctypes.c_float), _ptr(w, ctypes.c_uint8), wb, ws, _ptr(sw, ctypes.c_float), _ptr(zw, ctypes.c_float),
+        1 if sw.size == 1 else 0, _ptr(b, ctypes.c_float), B, K, O, MODES[mode],
+        _ptr(out, ctypes.c_float), _ptr(out64, ctypes.c_double)))
     return (out, out64) if return_f64 else out

@@ -18,7 +18,8 @@ DTYPES = {"uint8": 0, "int8": 1, "int16": 2, "int32": 3, "int64": 4,
 # every symbol include/quant_engine.h declares
 SYMBOLS = ["qe_error_string", "qe_last_hip_error", "qe_version", "qe_target_arch", "qe_packed_nbytes",
            "qe_tpack", "qe_tunpack", "qe_quantconv2d_workspace_bytes", "qe_quantconv2d",
-           "qe_quantconv2d_float_input", "qe_quantconv2d_path"]
+           "qe_quantconv2d_float_input", "qe_quantconv2d_path", "qe_quantlinear", "qe_quantlinear_float_input",
+           "qe_quantlinear_path"]
 
 
 class QeConvShape(ctypes.Structure):
@@ -64,6 +65,12 @@ def lib():
     L.qe_quantconv2d_float_input.argtypes = [vp, ctypes.POINTER(QeQParam), vp, ctypes.POINTER(QeConvShape), vp, vp]
     L.qe_quantconv2d_path.restype = i32
     L.qe_quantconv2d_path.argtypes = [ctypes.POINTER(QeConvShape), ctypes.POINTER(QeQParam), ctypes.POINTER(QeQParam)]
+    L.qe_quantlinear.restype = i32
+    L.qe_quantlinear.argtypes = [ctypes.POINTER(QeQParam), ctypes.POINTER(QeQParam), vp, i64, i32, i32, vp, vp]
+    L.qe_quantlinear_float_input.restype = i32
+    L.qe_quantlinear_float_input.argtypes = [vp, ctypes.POINTER(QeQParam), vp, i64, i32, i32, vp, vp]
+    L.qe_quantlinear_path.restype = i32
+    L.qe_quantlinear_path.argtypes = [ctypes.POINTER(QeQParam), ctypes.POINTER(QeQParam), i64, i32, i32]
     _lib = L
     return L
 
@@ -161,4 +168,29 @@ def quantconv2d_float_input(x, wq, bias, sh, out=None, stream=None):
     check(lib().qe_quantconv2d_float_input(x.data_ptr(), ctypes.byref(wq),
                                            None if bias is None else bias.data_ptr(), ctypes.byref(sh),
                                            out.data_ptr(), _stream(stream)))
+    return out
+
+
+def linear_path(xq, wq, B, K, O):
+    return int(lib().qe_quantlinear_path(ctypes.byref(xq), ctypes.byref(wq), int(B), int(K), int(O)))
+
+
+def quantlinear(xq, wq, bias, B, K, O, out=None, stream=None):
+    """out[b,o] = bias[o] + sum_k (qx + zx[b]) (qw + zw[o]) sx[b] sw[o]  (the reference kernel's (q + zero) convention)."""
+    import torch
+    if out is None:
+        out = torch.empty((B, O), dtype=torch.float32, device=wq._keep[0].device)
+    check(lib().qe_quantlinear(ctypes.byref(xq), ctypes.byref(wq), None if bias is None else bias.data_ptr(),
+                               int(B), int(K), int(O), out.data_ptr(), _stream(stream)))
+    return out
+
+
+def quantlinear_float_input(x, wq, bias, O, out=None, stream=None):
+    import torch
+    assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and x.dim() == 2
+    B, K = x.shape
+    if out is None:
+        out = torch.empty((B, O), dtype=torch.float32, device=x.device)
+    check(lib().qe_quantlinear_float_input(x.data_ptr(), ctypes.byref(wq), None if bias is None else bias.data_ptr(),
+                                           int(B), int(K), int(O), out.data_ptr(), _stream(stream)))
     return out

@@ -381,7 +381,7 @@ static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits, int w_bits)
 }
 
 // diagnostic (-DQE_STAMP) builds: where the kernels drop their per-wave phase sums
-static unsigned long long *g_mfma_dbg = nullptr;
+unsigned long long *g_mfma_dbg = nullptr;   // also read by qe_linear.hip (diagnostic builds)
 
 bool mfma_conv_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w)
 {

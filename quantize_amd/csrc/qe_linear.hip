@@ -1,0 +1,421 @@
+// qe_linear.hip -- quantlinear / quantlinear_float_input for gfx950 (MI355X).
+//
+// Replaces quantlinear_cuda_kernel (engine/kernels/functions/quantlinear.cu:39-133) and
+// quantlinear_float_input_cuda (functions/quantlinear_float_input.cu:36-104): 32x32 shared-memory tiles,
+// one output per thread, operands unpacked and dequantised to fp32 inside the K loop.
+//
+// A Linear is a GEMM whose two operands are both K-contiguous byte rows: exactly the MFMA operand order
+// (16 consecutive k per lane), so nothing has to be transposed.  8-bit x 8-bit problems run
+//   out[b,o] = bias[o] + sx[b] sw[o] ( S_aw + zw'[o] S_x[b] + zx'[b] S_w[o] + K zx'[b] zw'[o] )
+// with a = u ^ 0x80 (signed q, or unsigned q - 128; the 128 goes into z' = z + d), S_aw exact in int32 on
+// v_mfma_i32_32x32x32_i8, the row sums S_x / column sums S_w from v_dot4 on the same fragments.  The
+// per-ROW activation scale of this op (quantlinear.cu:96) is an epilogue factor like the per-column weight
+// scale, so every scale layout is eligible.  Everything else (sub-8-bit operands, fp32 input, K % 16 != 0)
+// goes to an order-preserving fp32 kernel that reproduces the reference's k-sequential chain bit for bit
+// (with fused multiply-add, as nvcc contracts it).
+#include "qe_common.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace qe {
+
+extern unsigned long long *g_mfma_dbg;   // qe_conv_mfma.hip: stamp buffer of -DQE_STAMP diagnostic builds
+
+#ifdef QE_STAMP
+__device__ __forceinline__ unsigned long long lin_stamp()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define LIN_ST(i) do { const unsigned long long _t = lin_stamp(); st[i] += _t - tprev; tprev = _t; } while (0)
+#else
+#define LIN_ST(i) do { } while (0)
+#endif
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int lin_unpack(const uint8_t *__restrict__ p, int64_t ele_idx, int n_bits, int sign)
+{
+    const int64_t bit = ele_idx * n_bits;
+    const int64_t byte = bit >> 3;
+    const int sh = (int)(bit & 7);
+    unsigned v = p[byte] >> sh;
+    if (sh + n_bits > 8) v |= (unsigned)p[byte + 1] << (8 - sh);
+    v &= (1u << n_bits) - 1u;
+    return sign ? (int)v - (1 << (n_bits - 1)) : (int)v;   // value after `-= offset; (T)value` (quantlinear.cu:113,118)
+}
+
+struct LinArgs {
+    const uint8_t *x;       // packed activations (or nullptr)
+    const float *xf;        // fp32 activations (float_input)
+    const uint8_t *w;
+    const float *x_scale, *x_zero, *w_scale, *w_zero, *bias;
+    int x_bits, x_sign, x_per_tensor, w_bits, w_sign, w_per_tensor;
+    int64_t B;
+    int K, O;
+    float *out;
+    unsigned long long *dbg;
+    int stagger, stagger_bit;   // workgroups with bit `stagger_bit` of their id set start `stagger` 64-cycle sleeps late
+};
+
+// ---------------------------------------------------------------------------------------------
+// Order-preserving fp32 kernel.  32x32 output tile per 256 threads (4 outputs per thread), 32-deep K
+// tiles of integer codes (or floats) in LDS; every output runs the reference's chain over k = 0..K-1:
+//   packed:      tmp = fmaf((qx + zx) * (qw + zw), sx * sw, tmp)   from 0, + bias last   (quantlinear.cu:113-131)
+//   float input: acc = fmaf(x, (qw - zw) * sw, acc)                from 0, + bias last   (float_input.cu:82-102)
+// ---------------------------------------------------------------------------------------------
+template <bool FLOAT_IN>
+__global__ __launch_bounds__(256) void linear_generic_kernel(const LinArgs a)
+{
+    __shared__ float sA[32][33];
+    __shared__ float sB[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // ty 0..7
+    const int n_ct = (a.O + 31) / 32;
+    const int64_t row0 = (int64_t)(blockIdx.x / n_ct) * 32;
+    const int col0 = (int)(blockIdx.x % n_ct) * 32;
+    const int col = col0 + tx;
+    const int colc = col < a.O ? col : a.O - 1;
+    const float zw = a.w_per_tensor ? a.w_zero[0] : a.w_zero[colc];
+    const float sw = a.w_per_tensor ? a.w_scale[0] : a.w_scale[colc];
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float zx[4], s[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t row = row0 + ty + 8 * i;
+        const int64_t rc = row < a.B ? row : a.B - 1;
+        if constexpr (FLOAT_IN) { zx[i] = 0.0f; s[i] = 0.0f; }
+        else {
+            zx[i] = a.x_per_tensor ? a.x_zero[0] : a.x_zero[rc];
+            s[i] = (a.x_per_tensor ? a.x_scale[0] : a.x_scale[rc]) * sw;      // quantlinear.cu:96
+        }
+    }
+    for (int k0 = 0; k0 < a.K; k0 += 32) {
+        // stage: sA[r][k] = activation (row0 + r, k0 + k), sB[c][k] = weight code (col0 + c, k0 + k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = ty + 8 * i;
+            const int64_t row = row0 + r;
+            const int k = k0 + tx;
+            float va = 0.0f, vb = 0.0f;
+            if (row < a.B && k < a.K)
+                va = FLOAT_IN ? a.xf[row * a.K + k] : (float)lin_unpack(a.x, row * a.K + k, a.x_bits, a.x_sign);
+            const int c = col0 + r;
+            if (c < a.O && k < a.K) vb = (float)lin_unpack(a.w, (int64_t)c * a.K + k, a.w_bits, a.w_sign);
+            sA[r][tx] = va;
+            sB[r][tx] = vb;
+        }
+        __syncthreads();
+        const int kn = min(32, a.K - k0);
+        for (int k = 0; k < kn; ++k) {
+            const float qw = sB[tx][k];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float xa = sA[ty + 8 * i][k];
+                if constexpr (FLOAT_IN) acc[i] = fmaf(xa, (qw - zw) * sw, acc[i]);
+                else acc[i] = fmaf((xa + zx[i]) * (qw + zw), s[i], acc[i]);
+            }
+        }
+        __syncthreads();
+    }
+    const float b = a.bias ? a.bias[colc] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t row = row0 + ty + 8 * i;
+        if (row < a.B && col < a.O) a.out[row * a.O + col] = acc[i] + b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// int8 MFMA GEMM, 8-bit x 8-bit, K % 64 == 0.
+// Workgroup = 256 threads = 2 x 2 waves; tile = 128 rows (batch) x 256 columns (output features); a wave owns
+// 64 x 128 = 2 x 4 MFMA tiles (128 accumulator registers): per 32-deep k-step it reads 2 A + 4 B fragments
+// from LDS for 8 MFMAs (24 B/clk/wave: under the CU's 128 B/clk, which a 64 x 64 wave tile would hit exactly).
+// Stage = 64 k of both operand tiles (8 + 16 KB), brought in by LDS-DMA (global_load_lds_dwordx4: no staging
+// registers) into a ring of 3 buffers, two stages ahead of the MFMAs: a register-staged single-stage prefetch
+// left the kernel latency-bound (12 stages x one HBM round trip each: 0.075 ms for 50432x768->768).  The DMA
+// writes lane-linear 16-byte pieces, so rows cannot be padded; bank conflicts are avoided by an XOR swizzle
+// applied on the SOURCE side (slot s of row r holds k-piece s ^ ((r >> 2) & 3)): the 16 rows of a ds_read_b128
+// phase then cover 16 distinct bank quads.  The u ^ 0x80 recode happens on the fragments.  One raw s_barrier per
+// stage (s_waitcnt vmcnt(pieces per stage) before it leaves the newest stage in flight; __syncthreads() would drain it).
+// D has the batch row on the register and the output feature on the lane: every store instruction writes two
+// full 128-byte lines of out[b][:].
+// ---------------------------------------------------------------------------------------------
+constexpr int LM = 128, LK = 64;
+constexpr int L_PA = LM * (LK / 16) / 256;   // A pieces per thread per stage (2)
+constexpr int L_RING = 3;
+
+// NJ = column tiles per wave: 4 (tile 128 x 256, 2 workgroups per CU) or 2 (tile 128 x 128, 3 per CU).
+template <int NJ>
+__global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a)
+{
+    constexpr int LN = 64 * NJ;
+    constexpr int L_PB = LN * (LK / 16) / 256;   // B pieces per thread per stage
+    constexpr int L_STAGE = (LM + LN) * LK;      // bytes per ring slot
+    extern __shared__ __attribute__((aligned(16))) uint8_t lsm[];   // [L_RING][A 128x64 | B 256x64] + rowc
+    float4 *rowc = reinterpret_cast<float4 *>(lsm + L_RING * L_STAGE);   // per batch row: sx, zx', S_x, K zx'
+    float4 *colc = rowc + LM;                                            // per output column: sw, zw', bias
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int col = lane & 31, h = lane >> 5;
+#ifdef QE_STAMP
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = lin_stamp();
+    const unsigned long long tstart = tprev;
+#endif
+    // column tiles fastest over neighbouring workgroups: they share the activation rows through L2
+    const int n_ct = (a.O + LN - 1) / LN;
+    const int64_t bid = blockIdx.x;
+    const int ct = (int)(bid % n_ct);
+    const int64_t rt = bid / n_ct;
+    const int64_t m0 = rt * LM;
+    const int n0 = ct * LN;
+
+    // De-phase the workgroups that share a CU.  All tiles cost the same, so the two (three) resident workgroups of a
+    // CU run in lock-step: both want the matrix pipe, then both (and every other CU) store at once, and the store
+    // phase is HBM-bound while the compute phase leaves HBM idle.  Workgroups of every other dispatch wave
+    // (256 workgroups = one per CU) start half a tile late, so stores of one overlap MFMAs of the other.
+    if (((bid >> a.stagger_bit) & 1) != 0) {
+        for (int i = 0; i < a.stagger; i += 127) __builtin_amdgcn_s_sleep(127);
+    }
+    // epilogue constants go to LDS now, while nothing else is in flight (loaded in the epilogue they cost a
+    // serialised global round trip per column tile)
+    const float dx = (a.x_sign ? 0.0f : 128.0f), dw = (a.w_sign ? 0.0f : 128.0f);   // a = q - d  ->  z' = z + d
+    if (tid < LM) {
+        const int64_t row = (m0 + tid < a.B) ? m0 + tid : a.B - 1;
+        const float sx = a.x_per_tensor ? a.x_scale[0] : a.x_scale[row];
+        const float zxp = (a.x_per_tensor ? a.x_zero[0] : a.x_zero[row]) + dx;
+        rowc[tid] = make_float4(sx, zxp, 0.0f, (float)a.K * zxp);
+    }
+    for (int c = tid; c < LN; c += 256) {
+        const int cc = (n0 + c < a.O) ? n0 + c : a.O - 1;
+        colc[c] = make_float4(a.w_per_tensor ? a.w_scale[0] : a.w_scale[cc],
+                              (a.w_per_tensor ? a.w_zero[0] : a.w_zero[cc]) + dw, a.bias ? a.bias[cc] : 0.0f, 0.0f);
+    }
+    __syncthreads();
+
+    // DMA pieces: LDS slot e = tid + 256 i <-> (row e >> 2, slot e & 3) receives k-piece (slot ^ swz(row)) of that row;
+    // rows past the end are clamped (valid memory, results never stored)
+    const int slot = tid & 3;
+    const uint8_t *pa[L_PA];
+    const uint8_t *pb[L_PB];
+#pragma unroll
+    for (int i = 0; i < L_PA; ++i) {
+        const int r = (tid + 256 * i) >> 2;
+        const int64_t row = (m0 + r < a.B) ? m0 + r : a.B - 1;
+        pa[i] = a.x + row * a.K + 16 * (slot ^ ((r >> 2) & 3));
+    }
+#pragma unroll
+    for (int i = 0; i < L_PB; ++i) {
+        const int r = (tid + 256 * i) >> 2;
+        const int c = (n0 + r < a.O) ? n0 + r : a.O - 1;
+        pb[i] = a.w + (int64_t)c * a.K + 16 * (slot ^ ((r >> 2) & 3));
+    }
+    auto issue = [&](int stage) __attribute__((always_inline)) {
+        uint8_t *buf = lsm + (stage % L_RING) * L_STAGE;
+        const int k0 = stage * LK;
+#pragma unroll
+        for (int i = 0; i < L_PA; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pa[i] + k0),
+                                             (__attribute__((address_space(3))) void *)(buf + (256 * i + 64 * wave) * 16), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < L_PB; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pb[i] + k0),
+                                             (__attribute__((address_space(3))) void *)(buf + LM * LK + (256 * i + 64 * wave) * 16), 16, 0, 0);
+    };
+
+    v16i acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+    int sxa[2] = {0, 0};           // this lane's share of S_x of its two row tiles (row = col, k half h)
+    int swa[NJ];                   // ... of S_w of its column tiles
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) swa[j] = 0;
+
+    const int n_stages = a.K / LK;
+    const int swz = (col >> 2) & 3;                       // (row >> 2) & 3 of this lane's fragment rows
+    const int a_off = (wm * 64 + col) * LK, b_off = LM * LK + (wn * 32 * NJ + col) * LK;
+    issue(0);
+    if (n_stages > 1) issue(1);
+    LIN_ST(0);   // prologue
+    for (int s = 0; s < n_stages; ++s) {
+        // stage s has landed for this wave once at most the L_PA + L_PB pieces of stage s+1 are still outstanding
+        if (s + 1 < n_stages) __builtin_amdgcn_s_waitcnt(0x0f70 | (L_PA + L_PB)); else __builtin_amdgcn_s_waitcnt(0x0f70);
+        LIN_ST(1);   // wait for the stage's DMA
+        __builtin_amdgcn_s_barrier();                     // ... for every wave; and ring slot (s+2)%3 is free again
+        LIN_ST(2);   // barrier
+        if (s + 2 < n_stages) issue(s + 2);
+        LIN_ST(3);   // DMA issue
+        const uint8_t *buf = lsm + (s % L_RING) * L_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < LK / 32; ++ks) {
+            const int po = 16 * ((2 * ks + h) ^ swz);
+            v4i fa[2], fb[NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const v4i *>(buf + a_off + i * 32 * LK + po);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const v4i *>(buf + b_off + j * 32 * LK + po);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    fa[i][q] ^= (int)0x80808080;          // u - 128: signed q, or unsigned q - 128
+                    sxa[i] = __builtin_amdgcn_sdot4(fa[i][q], 0x01010101, sxa[i], false);
+                }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    fb[j][q] ^= (int)0x80808080;
+                    swa[j] = __builtin_amdgcn_sdot4(fb[j][q], 0x01010101, swa[j], false);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        LIN_ST(4);   // fragment reads + MFMA
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------
+    // S_x joins the row constants (D has the row on the register, S_x lives on the lane that owns the row)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int sx_sum = sxa[i] + __shfl_xor(sxa[i], 32);
+        if (wn == 0 && h == 0) rowc[wm * 64 + i * 32 + col].z = (float)sx_sum;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int cl = wn * 32 * NJ + j * 32 + col;
+        const int c = n0 + cl;
+        const float4 cc = colc[cl];                       // sw, zw', bias
+        const float sws = (float)(swa[j] + __shfl_xor(swa[j], 32));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float4 rc = rowc[rl];
+                float v = (float)acc[i][j][r];
+                v = fmaf(cc.y, rc.z, v);
+                v = fmaf(rc.y, sws, v);
+                v = fmaf(rc.w, cc.y, v);
+                const int64_t row = m0 + rl;
+                if (row < a.B && c < a.O) a.out[row * a.O + c] = fmaf(rc.x * cc.x, v, cc.z);
+            }
+        }
+    }
+#ifdef QE_STAMP
+    LIN_ST(6);   // epilogue issue
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    LIN_ST(7);   // store drain
+    if (a.dbg != nullptr && lane == 0) {
+        unsigned long long *o = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 10;
+        for (int i = 0; i < 8; ++i) o[i] = st[i];
+        o[8] = tprev - tstart;
+        o[9] = tstart;
+    }
+#endif
+}
+template <int NJ> constexpr size_t lin_lds_bytes() { return (size_t)L_RING * (LM + 64 * NJ) * LK + (LM + 64 * NJ) * sizeof(float4); }
+
+static int check_lin_q(const qe_qparam *q, int64_t n_expected)
+{
+    if (q == nullptr || q->data == nullptr || q->scale == nullptr || q->zero == nullptr) return QE_ERR_ARG;
+    if (!(q->n_bits > 0 && q->n_bits <= 8)) return QE_ERR_NBITS;
+    if (q->n_param != 1 && q->n_param != n_expected) return QE_ERR_ARG;
+    return QE_OK;
+}
+
+static bool lin_mfma_eligible(const qe_qparam *x, const qe_qparam *w, int64_t B, int K, int O)
+{
+    return x->n_bits == 8 && w->n_bits == 8 && (K % LK) == 0 && K >= LK && B > 0 && O > 0 &&
+           (reinterpret_cast<uintptr_t>(x->data) & 15) == 0 && (reinterpret_cast<uintptr_t>(w->data) & 15) == 0;
+}
+
+}  // namespace qe
+
+extern "C" int qe_quantlinear_path(const qe_qparam *x, const qe_qparam *w, int64_t B, int32_t K, int32_t O)
+{
+    if (x == nullptr || w == nullptr) return 0;
+    return qe::lin_mfma_eligible(x, w, B, K, O) ? 1 : 0;
+}
+
+extern "C" int qe_quantlinear(const qe_qparam *x, const qe_qparam *w, const float *bias,
+                              int64_t B, int32_t K, int32_t O, float *out, qe_stream_t stream)
+{
+    using namespace qe;
+    if (B < 0 || K < 0 || O < 0) return QE_ERR_ARG;
+    int rc;
+    if ((rc = check_lin_q(x, B)) != QE_OK) return rc;
+    if ((rc = check_lin_q(w, O)) != QE_OK) return rc;
+    if (out == nullptr && B * O > 0) return QE_ERR_ARG;
+    if (B == 0 || O == 0) return QE_OK;
+    LinArgs a;
+    a.x = static_cast<const uint8_t *>(x->data); a.xf = nullptr; a.w = static_cast<const uint8_t *>(w->data);
+    a.x_scale = x->scale; a.x_zero = x->zero; a.w_scale = w->scale; a.w_zero = w->zero; a.bias = bias;
+    a.x_bits = x->n_bits; a.x_sign = x->sign; a.x_per_tensor = x->n_param == 1;
+    a.w_bits = w->n_bits; a.w_sign = w->sign; a.w_per_tensor = w->n_param == 1;
+    a.B = B; a.K = K; a.O = O; a.out = out; a.dbg = g_mfma_dbg;
+    a.stagger = getenv("QE_LIN_STAGGER") ? atoi(getenv("QE_LIN_STAGGER")) : 0;
+    a.stagger_bit = getenv("QE_LIN_STAGGER_BIT") ? atoi(getenv("QE_LIN_STAGGER_BIT")) : 8;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (lin_mfma_eligible(x, w, B, K, O)) {
+        // tile width: 256 columns unless that leaves the chip under-filled; QE_LIN_NJ=2|4 overrides (tuning)
+        int nj = 4;
+        if (const char *e = getenv("QE_LIN_NJ")) nj = atoi(e) == 2 ? 2 : 4;
+        const int ln = 64 * nj;
+        const int64_t blocks = ((B + LM - 1) / LM) * ((O + ln - 1) / ln);
+        if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
+        // more than 64 KB of dynamic LDS needs the attribute once
+        static const bool raised =
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_mfma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lin_lds_bytes<4>()) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lin_lds_bytes<2>()) == hipSuccess;
+        (void)raised;
+        if (nj == 4) hipLaunchKernelGGL(linear_mfma_kernel<4>, dim3((unsigned)blocks), dim3(256), lin_lds_bytes<4>(), s, a);
+        else         hipLaunchKernelGGL(linear_mfma_kernel<2>, dim3((unsigned)blocks), dim3(256), lin_lds_bytes<2>(), s, a);
+    } else {
+        const int64_t blocks = ((B + 31) / 32) * ((O + 31) / 32);
+        if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(linear_generic_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    }
+    QE_LAUNCH_CHECK();
+    return QE_OK;
+}
+
+extern "C" int qe_quantlinear_float_input(const float *x, const qe_qparam *w, const float *bias,
+                                          int64_t B, int32_t K, int32_t O, float *out, qe_stream_t stream)
+{
+    using namespace qe;
+    if (B < 0 || K < 0 || O < 0) return QE_ERR_ARG;
+    int rc;
+    if ((rc = check_lin_q(w, O)) != QE_OK) return rc;
+    if ((x == nullptr && B * K > 0) || (out == nullptr && B * O > 0)) return QE_ERR_ARG;
+    if (B == 0 || O == 0) return QE_OK;
+    LinArgs a;
+    a.x = nullptr; a.xf = x; a.w = static_cast<const uint8_t *>(w->data);
+    a.x_scale = nullptr; a.x_zero = nullptr; a.w_scale = w->scale; a.w_zero = w->zero; a.bias = bias;
+    a.x_bits = 0; a.x_sign = 0; a.x_per_tensor = 1;
+    a.w_bits = w->n_bits; a.w_sign = w->sign; a.w_per_tensor = w->n_param == 1;
+    a.B = B; a.K = K; a.O = O; a.out = out; a.dbg = nullptr; a.stagger = 0; a.stagger_bit = 8;
+    const int64_t blocks = ((B + 31) / 32) * ((O + 31) / 32);
+    if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(linear_generic_kernel<true>, dim3((unsigned)blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a);
+    QE_LAUNCH_CHECK();
+    return QE_OK;
+}

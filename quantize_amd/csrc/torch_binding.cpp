@@ -305,26 +305,102 @@ torch::Tensor conv2d(const torch::Tensor &input, const torch::Tensor &weight,
 }
 
 // ------------------------------------------------------------------------------------------
-// quantlinear / quantlinear_float_input (functions/quantlinear.cu:233-297,
-// functions/quantlinear_float_input.cu:120-182): SURVEY.md section 8f row 1, "next" -- not part of
-// the conv hot path.  They fail loudly rather than compute something else.
+// quantlinear  (reference: functions/quantlinear.cu:233-297, funcs.h:37-46)
+// Conventions of THIS reference kernel: (q + zero), activation scale/zero per batch ROW.
 // ------------------------------------------------------------------------------------------
-torch::Tensor quantlinear(const torch::Tensor &, const torch::Tensor &, const torch::Tensor &, const torch::Tensor &,
-                          const torch::Tensor &, const torch::Tensor &, const torch::Tensor &, const torch::Tensor &,
-                          const c10::optional<torch::Tensor> &)
+torch::Tensor quantlinear(const torch::Tensor &input, const torch::Tensor &input_des,
+                          const torch::Tensor &input_scale, const torch::Tensor &input_zero,
+                          const torch::Tensor &weight, const torch::Tensor &weight_des,
+                          const torch::Tensor &weight_scale, const torch::Tensor &weight_zero,
+                          const c10::optional<torch::Tensor> &bias)
 {
-    TORCH_CHECK(false, "quantlinear is not implemented in this build of quant_engine (gfx950): "
-                       "only the quantized conv2d path and tensor packing are (SURVEY.md section 8f).");
-    return {};
+    CHECK_INPUT(input);          // quantlinear.cu:245-252
+    CHECK_INPUT(weight);
+    CHECK_INPUT(input_des);
+    CHECK_INPUT(input_scale);
+    CHECK_INPUT(input_zero);
+    CHECK_INPUT(weight_des);
+    CHECK_INPUT(weight_scale);
+    CHECK_INPUT(weight_zero);
+    TORCH_CHECK(input_des.numel() >= 4 && weight_des.numel() >= 4,
+                "The description is too short, which should be at least 4.");
+    const Des xd = read_des(input_des);    // :255-257
+    const Des wd = read_des(weight_des);   // :258-260
+    CHECK_NBITS(xd.n_bits);
+    CHECK_NBITS(wd.n_bits);
+    const int64_t B = xd.shape[0], K = xd.shape[1], O = wd.shape[0];   // :272-274
+    TORCH_CHECK(K == wd.shape[1], "Input and weight do not match");    // :261
+    TORCH_CHECK(B >= 0 && K >= 0 && O >= 0 && K < (1ll << 31) && O < (1ll << 31), "invalid linear shape");
+    const float *bias_ptr = nullptr;
+    if (bias.has_value()) {
+        CHECK_INPUT(bias.value());
+        TORCH_CHECK(bias.value().scalar_type() == torch::kFloat, "expected scalar type Float but found ",
+                    toString(bias.value().scalar_type()));
+        TORCH_CHECK(O == bias.value().size(0), "Weight and bias do not match");   // :267
+        bias_ptr = bias.value().data_ptr<float>();
+    }
+    TORCH_CHECK(input.scalar_type() == torch::kByte, "expected scalar type Byte but found ", toString(input.scalar_type()));
+    TORCH_CHECK(weight.scalar_type() == torch::kByte, "expected scalar type Byte but found ", toString(weight.scalar_type()));
+    for (const torch::Tensor *t : {&input_scale, &input_zero, &weight_scale, &weight_zero})
+        TORCH_CHECK(t->scalar_type() == torch::kFloat, "expected scalar type Float but found ", toString(t->scalar_type()));
+    TORCH_CHECK(input.numel() >= qe_packed_nbytes(B * K, xd.n_bits), "The packed input is shorter than its description requires.");
+    TORCH_CHECK(weight.numel() >= qe_packed_nbytes(O * K, wd.n_bits), "The packed weight is shorter than its description requires.");
+    // The reference expands 0-dim scales (:276-290) and indexes anything else by row / column; a 1-element tensor
+    // is accepted as a broadcast too, anything else has to cover every row / column.
+    TORCH_CHECK(input_scale.numel() == input_zero.numel() && (input_scale.numel() == 1 || input_scale.numel() == B),
+                "input_scale/input_zero must hold 1 or batch_size elements");
+    TORCH_CHECK(weight_scale.numel() == weight_zero.numel() && (weight_scale.numel() == 1 || weight_scale.numel() == O),
+                "weight_scale/weight_zero must hold 1 or output_size elements");
+
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(input.device());
+    auto output = torch::empty({B, O}, torch::dtype(torch::kFloat32).device(input.device()));   // :166
+    const qe_qparam xq = make_qparam(input, xd, input_scale, input_zero);
+    const qe_qparam wq = make_qparam(weight, wd, weight_scale, weight_zero);
+    check_status(qe_quantlinear(&xq, &wq, bias_ptr, B, (int32_t)K, (int32_t)O, output.data_ptr<float>(),
+                                current_stream(input)), "quantlinear");
+    return output;
 }
 
-torch::Tensor quantlinear_float_input(const torch::Tensor &, const torch::Tensor &, const torch::Tensor &,
-                                      const torch::Tensor &, const torch::Tensor &,
-                                      const c10::optional<torch::Tensor> &)
+// ------------------------------------------------------------------------------------------
+// quantlinear_float_input  (reference: functions/quantlinear_float_input.cu:120-182, funcs.h:62-68)
+// ------------------------------------------------------------------------------------------
+torch::Tensor quantlinear_float_input(const torch::Tensor &input, const torch::Tensor &weight,
+                                      const torch::Tensor &weight_des, const torch::Tensor &weight_scale,
+                                      const torch::Tensor &weight_zero, const c10::optional<torch::Tensor> &bias)
 {
-    TORCH_CHECK(false, "quantlinear_float_input is not implemented in this build of quant_engine (gfx950): "
-                       "only the quantized conv2d path and tensor packing are (SURVEY.md section 8f).");
-    return {};
+    CHECK_INPUT(input);          // quantlinear_float_input.cu:129-138
+    CHECK_FLOAT(input);
+    CHECK_INPUT(weight);
+    CHECK_INPUT(weight_des);
+    CHECK_INPUT(weight_scale);
+    CHECK_INPUT(weight_zero);
+    if (bias.has_value()) { CHECK_INPUT(bias.value()); }
+    TORCH_CHECK(input.dim() == 2, "input must be a 2-D (batch_size, input_size) tensor");
+    TORCH_CHECK(weight_des.numel() >= 4, "The description is too short, which should be at least 4.");
+    const Des wd = read_des(weight_des);   // :141-143
+    CHECK_NBITS(wd.n_bits);
+    const int64_t B = input.size(0), K = input.size(1), O = wd.shape[0];   // :146-150
+    TORCH_CHECK(K == wd.shape[1], "Input and weight do not match");        // (the reference never compares them)
+    TORCH_CHECK(K < (1ll << 31) && O >= 0 && O < (1ll << 31), "invalid linear shape");
+    TORCH_CHECK(weight.scalar_type() == torch::kByte, "expected scalar type Byte but found ", toString(weight.scalar_type()));
+    for (const torch::Tensor *t : {&weight_scale, &weight_zero})
+        TORCH_CHECK(t->scalar_type() == torch::kFloat, "expected scalar type Float but found ", toString(t->scalar_type()));
+    TORCH_CHECK(weight.numel() >= qe_packed_nbytes(O * K, wd.n_bits), "The packed weight is shorter than its description requires.");
+    TORCH_CHECK(weight_scale.numel() == weight_zero.numel() && (weight_scale.numel() == 1 || weight_scale.numel() == O),
+                "weight_scale/weight_zero must hold 1 or output_size elements");
+    const float *bias_ptr = nullptr;
+    if (bias.has_value()) {
+        TORCH_CHECK(bias.value().scalar_type() == torch::kFloat, "expected scalar type Float but found ",
+                    toString(bias.value().scalar_type()));
+        TORCH_CHECK(bias.value().numel() >= O, "bias must hold output_size elements");
+        bias_ptr = bias.value().data_ptr<float>();
+    }
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(input.device());
+    auto output = torch::empty({B, O}, input.options());   // :153
+    const qe_qparam wq = make_qparam(weight, wd, weight_scale, weight_zero);
+    check_status(qe_quantlinear_float_input(input.data_ptr<float>(), &wq, bias_ptr, B, (int32_t)K, (int32_t)O,
+                                            output.data_ptr<float>(), current_stream(input)), "quantlinear_float_input");
+    return output;
 }
 
 }  // namespace
@@ -335,8 +411,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("tpack", &tpack, "tpack(x, n_bits, sign) -> [packed uint8 1-D, des int32]: b-bit LSB-first bit stream.");
     m.def("tunpack", &tunpack, "tunpack(packed, des) -> int8/uint8 tensor of shape des[2:].");
     m.def("linear", &linear, "linear(input, weight, bias, mode): float x @ w.T + b (ATen).");
-    m.def("quantlinear", &quantlinear, "quantlinear(...): not implemented in this build (raises).");
-    m.def("quantlinear_float_input", &quantlinear_float_input, "quantlinear_float_input(...): not implemented in this build (raises).");
+    m.def("quantlinear", &quantlinear,
+          "quantlinear(x, x_des, x_scale, x_zero, w, w_des, w_scale, w_zero, bias) -> fp32 (B, O); (q + zero), per-row x scale.");
+    m.def("quantlinear_float_input", &quantlinear_float_input,
+          "quantlinear_float_input(x_fp32, w, w_des, w_scale, w_zero, bias) -> fp32 (B, O); (q - zero) weights.");
     m.def("conv2d", &conv2d, "conv2d(input, weight, bias, stride, padding, mode): float conv (ATen).");
     m.def("quantconv2d", &quantconv2d,
           "quantconv2d(x, x_des, x_scale, x_zero, w, w_des, w_scale, w_zero, bias, stride, padding) -> fp32 NCHW.");

@@ -1,9 +1,10 @@
 """Operator surface of the quantized linear layer, mirroring the reference's
 modelzoo/modules/operator/quantlinearop.py:16-80 (QuantLinearOp1/2, quantlinear_forward).
 
-The dispatch table is the reference's; the two native functions behind it
-(engine.quantlinear / quantlinear_float_input) are SURVEY.md section 8f row 1 ("next") and
-raise RuntimeError in this build, so only the fp32 x fp32 -> F.linear branch computes.
+The dispatch table is the reference's; packed x packed goes to engine.quantlinear (int8 MFMA GEMM for
+8-bit operands), fp32 x packed to engine.quantlinear_float_input, fp32 x fp32 to F.linear.  Mind the
+conventions of the reference's linear kernel: quantlinear ADDS the zero point and indexes the activation
+scale by batch row (quantlinear.cu:96,115,120); quantlinear_float_input subtracts it (:82-86).
 """
 import torch
 from torch.autograd import Function

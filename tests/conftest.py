@@ -41,6 +41,16 @@ def g4():
     return Golden("g4_module.npz")
 
 
+@pytest.fixture(scope="session")
+def g5():
+    return Golden("g5_linear.npz")
+
+
+@pytest.fixture(scope="session")
+def g6():
+    return Golden("g6_linear_module.npz")
+
+
 def conv_tolerance(got, exact64, chain32):
     """Parity rule for the fp32 conv result (after SURVEY.md section 7, "fp32-order parity"): the
     reference accumulates K terms sequentially in fp32, so its own result is off the float64-exact
