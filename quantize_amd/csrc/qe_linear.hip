@@ -60,7 +60,6 @@ struct LinArgs {
     int K, O;
     float *out;
     unsigned long long *dbg;
-    int stagger, stagger_bit;   // workgroups with bit `stagger_bit` of their id set start `stagger` 64-cycle sleeps late
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -177,13 +176,6 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a)
     const int64_t m0 = rt * LM;
     const int n0 = ct * LN;
 
-    // De-phase the workgroups that share a CU.  All tiles cost the same, so the two (three) resident workgroups of a
-    // CU run in lock-step: both want the matrix pipe, then both (and every other CU) store at once, and the store
-    // phase is HBM-bound while the compute phase leaves HBM idle.  Workgroups of every other dispatch wave
-    // (256 workgroups = one per CU) start half a tile late, so stores of one overlap MFMAs of the other.
-    if (((bid >> a.stagger_bit) & 1) != 0) {
-        for (int i = 0; i < a.stagger; i += 127) __builtin_amdgcn_s_sleep(127);
-    }
     // epilogue constants go to LDS now, while nothing else is in flight (loaded in the epilogue they cost a
     // serialised global round trip per column tile)
     const float dx = (a.x_sign ? 0.0f : 128.0f), dw = (a.w_sign ? 0.0f : 128.0f);   // a = q - d  ->  z' = z + d
@@ -296,6 +288,13 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a)
         if (wn == 0 && h == 0) rowc[wm * 64 + i * 32 + col].z = (float)sx_sum;
     }
     __syncthreads();
+    // D has the batch row on the register and the feature on the lane.  Stored as is, every instruction is a
+    // dword store of two 128-byte row pieces, and the store phase (128 instructions per lane) was 40 % of a wave's
+    // life.  Each wave therefore turns its 32 x 32 tiles through a private LDS patch (the operand ring is free
+    // now) and writes 8 rows x 128 contiguous bytes per global_store_dwordx4: 4x fewer store instructions.
+    const bool vec4 = (a.O & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
+    float *patch = reinterpret_cast<float *>(lsm) + wave * (32 * 36);
+    const int rrow = lane >> 3, rq = lane & 7;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int cl = wn * 32 * NJ + j * 32 + col;
@@ -304,16 +303,36 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a)
         const float sws = (float)(swa[j] + __shfl_xor(swa[j], 32));
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const float4 rc = rowc[rl];
-                float v = (float)acc[i][j][r];
-                v = fmaf(cc.y, rc.z, v);
-                v = fmaf(rc.y, sws, v);
-                v = fmaf(rc.w, cc.y, v);
-                const int64_t row = m0 + rl;
-                if (row < a.B && c < a.O) a.out[row * a.O + c] = fmaf(rc.x * cc.x, v, cc.z);
+                float t = (float)acc[i][j][r];
+                t = fmaf(cc.y, rc.z, t);
+                t = fmaf(rc.y, sws, t);
+                t = fmaf(rc.w, cc.y, t);
+                v[r] = fmaf(rc.x * cc.x, t, cc.z);
+            }
+            if (vec4) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + col] = v[r];
+                __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): same wave wrote and reads
+                const int c4 = n0 + wn * 32 * NJ + j * 32 + 4 * rq;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int rt = 8 * k + rrow;
+                    const float4 o4 = *reinterpret_cast<const float4 *>(patch + rt * 36 + 4 * rq);
+                    const int64_t row = m0 + wm * 64 + i * 32 + rt;
+                    if (row < a.B && c4 < a.O) *reinterpret_cast<float4 *>(a.out + row * a.O + c4) = o4;
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);   // reads done before the next tile overwrites the patch
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < a.B && c < a.O) a.out[row * a.O + c] = v[r];
+                }
             }
         }
     }
@@ -369,8 +388,6 @@ extern "C" int qe_quantlinear(const qe_qparam *x, const qe_qparam *w, const floa
     a.x_bits = x->n_bits; a.x_sign = x->sign; a.x_per_tensor = x->n_param == 1;
     a.w_bits = w->n_bits; a.w_sign = w->sign; a.w_per_tensor = w->n_param == 1;
     a.B = B; a.K = K; a.O = O; a.out = out; a.dbg = g_mfma_dbg;
-    a.stagger = getenv("QE_LIN_STAGGER") ? atoi(getenv("QE_LIN_STAGGER")) : 0;
-    a.stagger_bit = getenv("QE_LIN_STAGGER_BIT") ? atoi(getenv("QE_LIN_STAGGER_BIT")) : 8;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (lin_mfma_eligible(x, w, B, K, O)) {
         // tile width: 256 columns unless that leaves the chip under-filled; QE_LIN_NJ=2|4 overrides (tuning)
@@ -411,7 +428,7 @@ extern "C" int qe_quantlinear_float_input(const float *x, const qe_qparam *w, co
     a.x_scale = nullptr; a.x_zero = nullptr; a.w_scale = w->scale; a.w_zero = w->zero; a.bias = bias;
     a.x_bits = 0; a.x_sign = 0; a.x_per_tensor = 1;
     a.w_bits = w->n_bits; a.w_sign = w->sign; a.w_per_tensor = w->n_param == 1;
-    a.B = B; a.K = K; a.O = O; a.out = out; a.dbg = nullptr; a.stagger = 0; a.stagger_bit = 8;
+    a.B = B; a.K = K; a.O = O; a.out = out; a.dbg = nullptr;
     const int64_t blocks = ((B + 31) / 32) * ((O + 31) / 32);
     if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(linear_generic_kernel<true>, dim3((unsigned)blocks), dim3(256), 0,
