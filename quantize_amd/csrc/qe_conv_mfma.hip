@@ -177,6 +177,8 @@ struct MfmaPlan {
     bool smallic = false;
     int GI = 1, NS = 1;
     bool flat = false, wraw = false, ws = false, s2 = false, sm2 = false;
+    bool expand = false;       // sub-8-bit activations are expanded to 8-bit codes in the workspace first
+    size_t xe_off = 0;
     int PADW = 0;
     size_t lds = 0;
     size_t wt_bytes = 0, ep_off = 0, ws_off = 0, total = 0;
@@ -188,7 +190,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static const int kNiw[3][3] = {{7, 4, 2}, {4, 2, 1}, {2, 1, 0}};
 static const int kWN[3] = {1, 2, 4};
 
-static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits, int w_bits)
+static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits)
 {
     MfmaPlan p;
     p.OH = (sh->H + 2 * sh->padding - sh->KH) / sh->stride + 1;
@@ -380,8 +382,26 @@ static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits, int w_bits)
     return p;
 }
 
+// Sub-8-bit activations: the halo kernel can decode them on the fly (8-byte clamped reads + shifts per 4 pixels),
+// but that path is 3-4x slower than the 8-bit kernels (ResNet-50 W4A4: 16.0 ms vs 4.7 ms per batch-256).  Instead
+// the stream is expanded once to signed 8-bit stored codes in the workspace (one pass at HBM rate: b/8 + 1 bytes per
+// element) and every fast 8-bit kernel applies.  QE_EXPAND=0 keeps the in-kernel decode (tuning / tests).
+static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits, int w_bits)
+{
+    const bool expand = x_bits < 8 && !(getenv("QE_EXPAND") && atoi(getenv("QE_EXPAND")) == 0);
+    MfmaPlan p = make_plan8(sh, expand ? 8 : x_bits, w_bits);
+    if (p.ok && expand) {
+        p.expand = true;
+        p.xe_off = align_up(p.total, 256);
+        p.total = p.xe_off + align_up((size_t)sh->N * sh->IC * sh->H * sh->W, 256);
+    }
+    return p;
+}
+
 // diagnostic (-DQE_STAMP) builds: where the kernels drop their per-wave phase sums
 unsigned long long *g_mfma_dbg = nullptr;   // also read by qe_linear.hip (diagnostic builds)
+
+int expand_codes_s8(const uint8_t *packed, int64_t n, int n_bits, int sign, uint8_t *out, hipStream_t s);   // qe_tpack.hip
 
 bool mfma_conv_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w)
 {
@@ -405,6 +425,17 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
         if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return QE_ERR_ARG;
     }
     uint8_t *wsp = static_cast<uint8_t *>(workspace);
+    qe_qparam xe;
+    if (p.expand) {
+        const int64_t n = (int64_t)sh->N * sh->IC * sh->H * sh->W;
+        const int rc = expand_codes_s8(static_cast<const uint8_t *>(x->data), n, x->n_bits, x->sign, wsp + p.xe_off, s);
+        if (rc != QE_OK) return rc;
+        xe = *x;
+        xe.data = wsp + p.xe_off;
+        xe.n_bits = 8;
+        xe.sign = 1;
+        x = &xe;
+    }
 
     PrepArgs pa;
     pa.w = w->data; pa.w_scale = w->scale; pa.w_zero = w->zero; pa.x_scale = x->scale; pa.bias = bias;

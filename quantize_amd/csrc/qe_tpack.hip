@@ -288,6 +288,35 @@ extern "C" int qe_tpack(const void *x, int dtype, int64_t n, int n_bits, int sig
     }
 }
 
+namespace qe {
+// Sub-8-bit packed stream -> one byte per element holding the SIGNED 8-bit stored code q + 128 (what tpack(q, 8, true)
+// would have produced).  The conv front end uses it to run b < 8 activations on the 8-bit MFMA kernels.  Same kernel
+// as tunpack: it computes (code - offset) mod 256, and q + 128 == code - offset + 128 == code - (offset + 128) mod 256.
+int expand_codes_s8(const uint8_t *packed, int64_t n, int n_bits, int sign, uint8_t *out, hipStream_t s)
+{
+    if (!(n_bits > 0 && n_bits < 8)) return QE_ERR_NBITS;
+    if (n <= 0) return QE_OK;
+    const int64_t n_in = qe_packed_nbytes(n, n_bits);
+    const unsigned offset = ((sign ? (1u << (n_bits - 1)) : 0u) + 128u) & 0xffu;
+    const int64_t n_tiles = (n + TP_TILE - 1) / TP_TILE;
+    const int blocks = (int)(n_tiles < TP_MAX_BLOCKS ? n_tiles : TP_MAX_BLOCKS);
+    const int in_al = ((uintptr_t)packed % 16) == 0;
+    const int out_al = ((uintptr_t)out % 16) == 0;
+#define QE_EX_CASE(BITS)                                                                              \
+    case BITS:                                                                                        \
+        hipLaunchKernelGGL((tunpack_kernel<BITS>), dim3(blocks), dim3(TP_THREADS), 0, s, packed, out, \
+                           n, n_in, offset, in_al, out_al);                                           \
+        break;
+    switch (n_bits) {
+        QE_EX_CASE(1) QE_EX_CASE(2) QE_EX_CASE(3) QE_EX_CASE(4) QE_EX_CASE(5) QE_EX_CASE(6) QE_EX_CASE(7)
+        default: return QE_ERR_NBITS;
+    }
+#undef QE_EX_CASE
+    QE_LAUNCH_CHECK();
+    return QE_OK;
+}
+}  // namespace qe
+
 extern "C" int qe_tunpack(const uint8_t *packed, int64_t n, int n_bits, int sign,
                           void *out, qe_stream_t stream)
 {

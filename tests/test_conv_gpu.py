@@ -272,3 +272,27 @@ def test_kernel_variants_forced_by_env(engine, env):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+@pytest.mark.parametrize("expand", ["0", "1"])
+def test_sub8_activation_paths(engine, expand):
+    """b < 8 activations either decode inside the halo kernel (QE_EXPAND=0) or are expanded once to 8-bit codes in
+    the workspace and run on the 8-bit kernels (default); both meet the parity bar, incl. asymmetric zero points."""
+    import os
+    rng = np.random.RandomState(23)
+    old = os.environ.get("QE_EXPAND")
+    os.environ["QE_EXPAND"] = expand
+    try:
+        for shp in [(2, 64, 28, 28, 160, 1, 1, 0), (2, 128, 14, 14, 130, 3, 1, 1), (3, 64, 56, 56, 64, 3, 1, 1),
+                    (2, 3, 37, 41, 24, 7, 2, 3), (2, 96, 28, 28, 130, 1, 2, 0), (5, 96, 7, 7, 64, 1, 1, 0)]:
+            for (wb, wsgn, ab, asgn) in [(4, 1, 4, 1), (8, 1, 4, 0), (3, 0, 6, 1), (8, 0, 1, 0)]:
+                for zeros in (False, True):
+                    case = _random_case(rng, *shp, wb, wsgn, ab, asgn, w_pc=True, a_pc=False, zeros=zeros, bias=True)
+                    y, o32, o64 = _run_case(engine, case, via_capi=True)
+                    assert case["path"] == 1
+                    _assert_conv_close(y, o64, o32, "expand=%s %s %s zeros=%s" % (expand, shp, (wb, wsgn, ab, asgn), zeros))
+    finally:
+        if old is None:
+            os.environ.pop("QE_EXPAND", None)
+        else:
+            os.environ["QE_EXPAND"] = old
