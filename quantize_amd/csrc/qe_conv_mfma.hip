@@ -50,6 +50,7 @@ struct PrepArgs {
     const float *bias;
     int w_bits, w_sign, w_per_tensor;
     int OC, IC, KK, OCP, NG;
+    int KH, KW;
     int8_t *wt;
     float *ep;
     int *ws;
@@ -99,13 +100,18 @@ __global__ __launch_bounds__(256) void conv_mfma_prep_kernel(const PrepArgs a)
         if (sum != 0) atomicAdd(&s_ws[tap], sum);
     }
     __syncthreads();
-    if (tid < a.KK) a.ws[oc * (a.KK + 1) + tid] = s_ws[tid];
-    if (tid == 64) {
-        int all = 0;
-        for (int t = 0; t < a.KK; ++t) all += s_ws[t];
-        a.ws[oc * (a.KK + 1) + a.KK] = all;
+    // 2-D prefix table of the per-tap sums: P[i][j] = sum over kh < i, kw < j (border-aware S_w in O(1), epilogue)
+    {
+        const int PW1 = a.KW + 1, PS = (a.KH + 1) * PW1;
+        if (tid < PS) {
+            const int i = tid / PW1, j = tid - i * PW1;
+            int sum = 0;
+            for (int kh = 0; kh < i; ++kh)
+                for (int kw = 0; kw < j; ++kw) sum += s_ws[kh * a.KW + kw];
+            a.ws[(int64_t)oc * PS + tid] = sum;
+        }
     }
-    if (tid == 65) {
+    if (tid == 128) {
         float alpha = 0.0f, zwp = 0.0f, b = 0.0f;
         if (live) {
             const float sw = a.w_per_tensor ? a.w_scale[0] : a.w_scale[oc];
@@ -147,11 +153,17 @@ __global__ __launch_bounds__(64) void conv_mfma_prep_smallic_kernel(const PrepAr
         *reinterpret_cast<uint4 *>(a.wt + (((int64_t)kh * 2 + h) * a.OCP + oc) * 16) = make_uint4(v[0], v[1], v[2], v[3]);
     }
     __syncthreads();
-    if (tid < a.KK) a.ws[oc * (a.KK + 1) + tid] = s_ws[tid];
+    {
+        const int PW1 = KW + 1, PS = (KH + 1) * PW1;
+        for (int e = tid; e < PS; e += 64) {
+            const int i = e / PW1, j = e - i * PW1;
+            int sum = 0;
+            for (int kh = 0; kh < i; ++kh)
+                for (int kw = 0; kw < j; ++kw) sum += s_ws[kh * KW + kw];
+            a.ws[(int64_t)oc * PS + e] = sum;
+        }
+    }
     if (tid == 0) {
-        int all = 0;
-        for (int t = 0; t < a.KK; ++t) all += s_ws[t];
-        a.ws[oc * (a.KK + 1) + a.KK] = all;
         float alpha = 0.0f, zwp = 0.0f, b = 0.0f;
         if (live) {
             const float sw = a.w_per_tensor ? a.w_scale[0] : a.w_scale[oc];
@@ -377,7 +389,7 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits)
     if (p.flat && p.wraw) { p.total = 0; p.ok = true; return p; }
     p.ep_off = align_up(p.wt_bytes, 256);
     p.ws_off = align_up(p.ep_off + (size_t)3 * p.OCP * sizeof(float), 256);
-    p.total = align_up(p.ws_off + (size_t)p.OCP * (p.KK + 1) * sizeof(int), 256);
+    p.total = align_up(p.ws_off + (size_t)p.OCP * (sh->KH + 1) * (sh->KW + 1) * sizeof(int), 256);
     p.ok = true;
     return p;
 }
@@ -440,7 +452,7 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     PrepArgs pa;
     pa.w = w->data; pa.w_scale = w->scale; pa.w_zero = w->zero; pa.x_scale = x->scale; pa.bias = bias;
     pa.w_bits = w->n_bits; pa.w_sign = w->sign; pa.w_per_tensor = (w->n_param == 1);
-    pa.OC = sh->OC; pa.IC = sh->IC; pa.KK = p.KK; pa.OCP = p.OCP; pa.NG = p.NG;
+    pa.OC = sh->OC; pa.IC = sh->IC; pa.KK = p.KK; pa.OCP = p.OCP; pa.NG = p.NG; pa.KH = sh->KH; pa.KW = sh->KW;
     pa.wt = reinterpret_cast<int8_t *>(wsp);
     pa.ep = reinterpret_cast<float *>(wsp + p.ep_off);
     pa.ws = reinterpret_cast<int *>(wsp + p.ws_off);

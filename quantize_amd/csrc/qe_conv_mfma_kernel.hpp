@@ -25,7 +25,7 @@ struct MfmaArgs {
     int x_bits, x_sign;
     const int8_t *wt;          // [KK][NG][OCP][16]
     const float *ep;           // [3][OCP]: alpha = sx*sw, zw', bias
-    const int *ws;             // [OCP][KK+1]: sum_ic a_w per tap, [KK] = all taps
+    const int *ws;             // [OCP][(KH+1)*(KW+1)]: 2-D prefix sums over (kh, kw) of sum_ic a_w; last entry = all taps
     float *out;
     int N, IC, H, W, OC, KH, KW, stride, pad, OH, OW;
     int OCP, NG, NCH;          // padded oc, 16-channel groups (even), 32-channel chunks
@@ -181,28 +181,37 @@ __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW
             }
         }
     } else {
+        // asymmetric operands.  S_w of a pixel = sum of the per-tap weight sums over the taps INSIDE the image (the
+        // reference skips padded taps, quantconv2d.cu:101).  The in-bounds taps of a pixel form a kh-range x kw-range,
+        // so S_w comes from the 2-D prefix table the prep pass leaves in a.ws ([oc][(KH+1) x (KW+1)]): interior
+        // pixels use the per-channel total (one load per channel, hoisted out of the tile loop), border pixels four
+        // table entries.  No per-tap loop, no per-element table walk (the first version cost 3-6x on 3x3 layers and
+        // 17x on the 7x7 stem).
         float zw[16];
+        int swt[16];
+        const int PW1 = a.KW + 1, PS = (a.KH + 1) * PW1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) zw[r] = a.ep[a.OCP + oc_base + (r & 3) + 8 * (r >> 2)];
+        for (int r = 0; r < 16; ++r) {
+            const int oc = oc_base + (r & 3) + 8 * (r >> 2);
+            zw[r] = a.ep[a.OCP + oc];
+            swt[r] = need_sw ? a.ws[(int64_t)oc * PS + PS - 1] : 0;
+        }
 #pragma unroll
         for (int t = 0; t < NIW; ++t) {
             const int q = (wn + t * WN) * 32 + col;
-            // in-bounds taps of this pixel: the reference skips padded taps (quantconv2d.cu:101)
-            unsigned long long mask = 0;
-            int n_inb = 0;
-            bool interior = true;
+            int kh_lo = 0, kh_hi = a.KH, kw_lo = 0, kw_hi = a.KW;
             {
                 const int gi = valid[t] ? q / g.OHWt : 0;
                 const int rq = valid[t] ? q - gi * g.OHWt : 0;
                 const int r = rq / a.OW, c = rq - r * a.OW;
                 const int ihb = (g.oh0 + r) * a.stride - a.pad, iwb = c * a.stride - a.pad;
-                for (int tap = 0; tap < KK; ++tap) {
-                    const int kh = tap / a.KW, kw = tap - kh * a.KW;
-                    const bool inb = (ihb + kh) >= 0 && (ihb + kh) < a.H && (iwb + kw) >= 0 && (iwb + kw) < a.W;
-                    if (inb) { mask |= 1ull << tap; ++n_inb; } else interior = false;
-                }
+                kh_lo = max(0, -ihb); kh_hi = max(kh_lo, min(a.KH, a.H - ihb));
+                kw_lo = max(0, -iwb); kw_hi = max(kw_lo, min(a.KW, a.W - iwb));
             }
+            const int n_inb = (kh_hi - kh_lo) * (kw_hi - kw_lo);
+            const bool interior = n_inb == KK;
             const float fn = (float)(n_inb * a.IC);
+            const int i11 = kh_hi * PW1 + kw_hi, i01 = kh_lo * PW1 + kw_hi, i10 = kh_hi * PW1 + kw_lo, i00 = kh_lo * PW1 + kw_lo;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int dr = (r & 3) + 8 * (r >> 2);
@@ -210,12 +219,10 @@ __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW
                 float v = (float)acc[t][r];
                 v = fmaf(-zw[r], (float)sxs[t], v);
                 if (need_sw) {
-                    const int *wsr = a.ws + (int64_t)oc * (KK + 1);
-                    int sw_sum = wsr[KK];
+                    int sw_sum = swt[r];
                     if (!interior) {
-                        sw_sum = 0;
-                        for (int tap = 0; tap < KK; ++tap)
-                            if ((mask >> tap) & 1ull) sw_sum += wsr[tap];
+                        const int *P = a.ws + (int64_t)oc * PS;
+                        sw_sum = P[i11] - P[i01] - P[i10] + P[i00];
                     }
                     v = fmaf(-zxp, (float)sw_sum, v);
                     v = fmaf(fn * zxp, zw[r], v);
