@@ -44,7 +44,7 @@ def parse_args():
     ap.add_argument("--asymmetric", action="store_true", help="unsigned activations with z_x = 133.2578 (SURVEY 8d)")
     ap.add_argument("--per-layer", action="store_true", help="also time every layer on its own (untimed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=2, help="images of the CPU-baseline sample")
+    ap.add_argument("--cpu-images", type=int, default=16, help="images of the CPU-baseline sample (about 15 s on 16 cores)")
     ap.add_argument("--layers", type=str, default="", help="comma list of layer indices (debug)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the 53 layer calls as one captured hipGraph instead of launching them one by one "
