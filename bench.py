@@ -43,6 +43,9 @@ def parse_args():
     ap.add_argument("--a-bits", type=int, default=8)
     ap.add_argument("--asymmetric", action="store_true", help="unsigned activations with z_x = 133.2578 (SURVEY 8d)")
     ap.add_argument("--per-layer", action="store_true", help="also time every layer on its own (untimed region)")
+    ap.add_argument("--cold", action="store_true",
+                    help="--per-layer: overwrite 1 GiB before every timed call, so inputs come from HBM as they do inside "
+                         "the stack (repeating one layer keeps its input in the 256 MB Infinity Cache otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=16, help="images of the CPU-baseline sample (about 15 s on 16 cores)")
     ap.add_argument("--layers", type=str, default="", help="comma list of layer indices (debug)")
@@ -226,15 +229,27 @@ def main():
         per_layer = []
         reps = 5
         with torch.cuda.stream(stream):
+            flush = torch.empty(1 << 28, dtype=torch.float32, device=dev) if args.cold else None
             for L in layers:
                 L.run(sp)
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(stream)
-                for _ in range(reps):
-                    L.run(sp)
-                b.record(stream)
-                stream.synchronize()
-                ms = a.elapsed_time(b) / reps
+                if args.cold:
+                    ms = 0.0
+                    for _ in range(reps):
+                        flush.fill_(1.0)
+                        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        a.record(stream)
+                        L.run(sp)
+                        b.record(stream)
+                        stream.synchronize()
+                        ms += a.elapsed_time(b) / reps
+                else:
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(stream)
+                    for _ in range(reps):
+                        L.run(sp)
+                    b.record(stream)
+                    stream.synchronize()
+                    ms = a.elapsed_time(b) / reps
                 per_layer.append({"i": L.idx, "name": L.spec.name,
                                   "shape": [L.spec.IC, L.spec.OC, L.spec.K, L.spec.stride, L.spec.pad, L.spec.H],
                                   "path": "mfma" if L.path else "generic", "ms": round(ms, 4),

@@ -318,7 +318,14 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits)
         p.NCH = 1;
         p.NG = 2;
         p.niw = kNiw[p.cfg][0];
-        int TH = std::min(p.OH, (32 * max_tiles) / p.OW);
+        int stem_tiles = max_tiles;
+        // 64-channel workgroups (the ResNet stem): 7 column tiles per wave = 4 output rows per tile instead of 2
+        // (fewer, larger workgroups: less halo re-read, prologue amortised).  QE_STEM_NIW=4 restores the old tiles.
+        if (p.cfg == 1 && !(getenv("QE_STEM_NIW") && atoi(getenv("QE_STEM_NIW")) == 4) && p.OW <= 32 * 14) {
+            p.niw = 7;
+            stem_tiles = 14;
+        }
+        int TH = std::min(p.OH, (32 * stem_tiles) / p.OW);
         for (; TH >= 1; --TH) {
             const int IHT = (TH - 1) * sh->stride + sh->KH;
             const int IWP = (p.OW - 1) * sh->stride + 8;
@@ -528,7 +535,7 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
         return QE_OK;
     }
     if (p.smallic) {
-        launch_mfma_smallic(a, p.cfg, (unsigned)blocks, p.lds, s);
+        launch_mfma_smallic(a, p.cfg, p.niw, (unsigned)blocks, p.lds, s);
         QE_LAUNCH_CHECK();
         return QE_OK;
     }

@@ -1530,7 +1530,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
 void launch_mfma_cfg0(const MfmaArgs &a, int niw, int ns, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_cfg1(const MfmaArgs &a, int niw, int ns, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_cfg2(const MfmaArgs &a, int niw, int ns, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
-void launch_mfma_smallic(const MfmaArgs &a, int cfg, unsigned blocks, size_t lds, hipStream_t s);
+void launch_mfma_smallic(const MfmaArgs &a, int cfg, int niw, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_ws(const MfmaArgs &a, int niw, int split, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_sm2(const MfmaArgs &a, int wms, int split, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_flat(const MfmaArgs &a, int cfg, int niw, int ns, bool wraw, bool s2, unsigned blocks, size_t lds, hipStream_t s);

@@ -157,6 +157,8 @@ SWEEP_SHAPES = [
     (3, 40, 9, 9, 48, 3, 1, 1),      # 3x3 two-strip kernel, 64-channel workgroups, several images per tile
     (2, 70, 20, 20, 130, 3, 2, 1),   # 3x3 two-strip kernel, stride 2, partial oc tile, padded last chunk
     (1, 64, 56, 56, 64, 3, 1, 1),    # 3x3 two-strip kernel, 14 column tiles over 4 pixel waves
+    (2, 3, 40, 40, 64, 7, 2, 3),     # stem kernel, 64-channel workgroups with 14 column tiles
+    (1, 4, 20, 24, 48, 5, 1, 2),     # stem kernel, 4 input channels, 5x5
 ]
 
 

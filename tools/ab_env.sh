@@ -1,8 +1,9 @@
 #!/bin/bash
 # A/B an environment knob over the per-layer isolated times: tools/ab_env.sh VAR v1 v2 ...
+# AB_EXTRA=--cold times every call after a 1 GiB overwrite (inputs from HBM, as inside the stack)
 VAR=$1; shift
 for v in "$@"; do
-  env $VAR=$v timeout -k 10 300 python bench.py --steps 3 --warmup 1 --per-layer --no-cpu-baseline > gpurun_out/ab_${VAR}_$v.json 2> gpurun_out/ab_${VAR}_$v.err
+  env $VAR=$v timeout -k 10 300 python bench.py --steps 3 --warmup 1 --per-layer $AB_EXTRA --no-cpu-baseline > gpurun_out/ab_${VAR}_$v.json 2> gpurun_out/ab_${VAR}_$v.err
 done
 python - "$VAR" "$@" <<'PY'
 import re, sys, json
