@@ -1149,32 +1149,50 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_smallic_kernel(const 
     const int HW = a.H * a.W;
     const uint8_t *xi = a.x + (int64_t)n * a.IC * HW;
     const int ones = a.IC >= 4 ? 0x01010101 : (0x01010101 & ((1 << (8 * a.IC)) - 1));
-    for (int uid = tid; uid < a.IHT * NQ; uid += MF_THREADS) {
-        const int l = uid / NQ, iq = uid - l * NQ;
-        const int ih = ih0 + l;
-        const bool ok = ih >= 0 && ih < a.H;
-        int iw0 = 4 * iq, sh = 0;
-        if (iw0 + 4 > a.W) { sh = 8 * (iw0 + 4 - a.W); iw0 = a.W - 4; }
-        const uint32_t off = ok ? (uint32_t)(ih * a.W + iw0) : 0u;
-        uint32_t dch[4];
+    // All loads of up to 4 units per thread are issued before the first one is consumed (a plain loop over the
+    // units waits for each unit's loads before it requests the next: three dependent HBM round trips per tile).
+    const int n_units = a.IHT * NQ;
+    for (int u0 = 0; u0 < n_units; u0 += 4 * MF_THREADS) {
+        uint32_t dch[4][4];
+        int ul[4], uq[4], ush[4];
+        bool uok[4], ulive[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int icc = i < a.IC ? i : a.IC - 1;       // uniform
-            uint32_t v;
-            __builtin_memcpy(&v, xi + (int64_t)icc * HW + off, 4);
-            dch[i] = (i < a.IC) ? ((v >> sh) ^ 0x80808080u) : 0u;  // uniform select; padded channel = 0
+        for (int it = 0; it < 4; ++it) {
+            const int uid = u0 + tid + it * MF_THREADS;
+            ulive[it] = uid < n_units;
+            const int uc = ulive[it] ? uid : 0;
+            const int l = uc / NQ, iq = uc - l * NQ;
+            const int ih = ih0 + l;
+            const bool ok = ih >= 0 && ih < a.H;
+            int iw0 = 4 * iq, sh = 0;
+            if (iw0 + 4 > a.W) { sh = 8 * (iw0 + 4 - a.W); iw0 = a.W - 4; }
+            const uint32_t off = ok ? (uint32_t)(ih * a.W + iw0) : 0u;
+            ul[it] = l; uq[it] = iq; ush[it] = sh; uok[it] = ok;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int icc = i < a.IC ? i : a.IC - 1;       // uniform
+                uint32_t v;
+                __builtin_memcpy(&v, xi + (int64_t)icc * HW + off, 4);
+                dch[it][i] = v;
+            }
         }
-        uint32_t o0, o1, o2, o3;
-        transpose4x4(dch[0], dch[1], dch[2], dch[3], o0, o1, o2, o3);
-        const uint32_t o[4] = {o0, o1, o2, o3};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int iw = 4 * iq + j;
-            const int cl = iw + a.pad;
-            const bool pok = ok && iw < a.W && cl < a.IWP;
-            const int idx = pok ? l * a.IWP + cl : trash;
-            Xs[idx] = o[j];
-            if (need_sx && pok) sxp[idx] = __builtin_amdgcn_sdot4((int)o[j], ones, 0, false);
+        for (int it = 0; it < 4; ++it) {
+            uint32_t c4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c4[i] = (i < a.IC) ? ((dch[it][i] >> ush[it]) ^ 0x80808080u) : 0u;  // padded channel = 0
+            uint32_t o0, o1, o2, o3;
+            transpose4x4(c4[0], c4[1], c4[2], c4[3], o0, o1, o2, o3);
+            const uint32_t o[4] = {o0, o1, o2, o3};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iw = 4 * uq[it] + j;
+                const int cl = iw + a.pad;
+                const bool pok = ulive[it] && uok[it] && iw < a.W && cl < a.IWP;
+                const int idx = pok ? ul[it] * a.IWP + cl : trash;
+                Xs[idx] = o[j];
+                if (need_sx && pok) sxp[idx] = __builtin_amdgcn_sdot4((int)o[j], ones, 0, false);
+            }
         }
     }
     __syncthreads();
