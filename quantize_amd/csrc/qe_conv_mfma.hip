@@ -191,6 +191,8 @@ struct MfmaPlan {
     bool flat = false, wraw = false, ws = false, s2 = false, sm2 = false;
     bool expand = false;       // sub-8-bit activations are expanded to 8-bit codes in the workspace first
     size_t xe_off = 0;
+    bool sub = false;          // strided 1x1: the sampled pixels are gathered into a dense tensor first
+    size_t sub_off = 0;
     int PADW = 0;
     size_t lds = 0;
     size_t wt_bytes = 0, ep_off = 0, ws_off = 0, total = 0;
@@ -405,16 +407,74 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits)
 // but that path is 3-4x slower than the 8-bit kernels (ResNet-50 W4A4: 16.0 ms vs 4.7 ms per batch-256).  Instead
 // the stream is expanded once to signed 8-bit stored codes in the workspace (one pass at HBM rate: b/8 + 1 bytes per
 // element) and every fast 8-bit kernel applies.  QE_EXPAND=0 keeps the in-kernel decode (tuning / tests).
+// the dense problem a strided 1x1 / pad 0 convolution reduces to: out[n,oc,oh,ow] only ever reads x[n,c,oh*s,ow*s]
+static qe_conv_shape dense_shape(const qe_conv_shape *sh)
+{
+    qe_conv_shape d = *sh;
+    d.H = (sh->H - 1) / sh->stride + 1;
+    d.W = (sh->W - 1) / sh->stride + 1;
+    d.stride = 1;
+    return d;
+}
+
 static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits, int w_bits)
 {
     const bool expand = x_bits < 8 && !(getenv("QE_EXPAND") && atoi(getenv("QE_EXPAND")) == 0);
-    MfmaPlan p = make_plan8(sh, expand ? 8 : x_bits, w_bits);
+    const int xb = expand ? 8 : x_bits;
+    // Strided 1x1 (the ResNet downsample branches): gather the sampled pixels once (read every other row, write 1/s^2 of
+    // the bytes) and run the stride-1 kernels on the dense tensor, instead of staging 2-4x the needed bytes in every
+    // one of the OC/128 workgroups that share a pixel tile.  QE_SUBSAMPLE=0 keeps the in-kernel strided staging.
+    const bool sub = sh->KH == 1 && sh->KW == 1 && sh->stride > 1 && sh->padding == 0 && xb == 8 &&
+                     !(getenv("QE_SUBSAMPLE") && atoi(getenv("QE_SUBSAMPLE")) == 0);
+    const qe_conv_shape ds = dense_shape(sh);
+    MfmaPlan p = make_plan8(sub ? &ds : sh, xb, w_bits);
+    if (p.ok && sub) {
+        p.sub = true;
+        p.sub_off = align_up(p.total, 256);
+        p.total = p.sub_off + align_up((size_t)ds.N * ds.IC * ds.H * ds.W, 256);
+    } else if (sub) {
+        p = make_plan8(sh, xb, w_bits);
+    }
     if (p.ok && expand) {
         p.expand = true;
         p.xe_off = align_up(p.total, 256);
         p.total = p.xe_off + align_up((size_t)sh->N * sh->IC * sh->H * sh->W, 256);
     }
     return p;
+}
+
+// out[r][ow] = in[r_in][ow * s] for the rows r = (n*IC + c)*OH + oh: one thread per 4 output bytes.
+__global__ __launch_bounds__(256) void subsample_kernel(const uint8_t *__restrict__ x, uint8_t *__restrict__ y, int64_t n_planes,
+                                                        int H, int W, int OH, int OW, int s)
+{
+    const int nq = (OW + 3) >> 2;
+    const int64_t total = n_planes * OH * nq;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / nq;
+        const int q = (int)(i - r * nq);
+        const int64_t plane = r / OH;
+        const int oh = (int)(r - plane * OH);
+        const uint8_t *src = x + (plane * H + (int64_t)oh * s) * W;
+        const int ow0 = 4 * q;
+        uint32_t v = 0;
+        if (s == 2 && 2 * ow0 + 8 <= W) {
+            uint32_t d[2];
+            __builtin_memcpy(d, src + 2 * ow0, 8);                   // 8 input bytes, keep the even ones
+            v = __builtin_amdgcn_perm(d[1], d[0], 0x06040200u);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (ow0 + j < OW) v |= (uint32_t)src[(int64_t)(ow0 + j) * s] << (8 * j);
+        }
+        uint8_t *dst = y + r * OW + ow0;
+        if (ow0 + 4 <= OW && (reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
+            *reinterpret_cast<uint32_t *>(dst) = v;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (ow0 + j < OW) dst[j] = (uint8_t)(v >> (8 * j));
+        }
+    }
 }
 
 // diagnostic (-DQE_STAMP) builds: where the kernels drop their per-wave phase sums
@@ -454,6 +514,21 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
         xe.n_bits = 8;
         xe.sign = 1;
         x = &xe;
+    }
+    qe_qparam xs;
+    qe_conv_shape shd;
+    if (p.sub) {
+        shd = dense_shape(sh);
+        const int64_t n_planes = (int64_t)sh->N * sh->IC;
+        const int64_t threads = n_planes * shd.H * ((shd.W + 3) / 4);
+        const int64_t blocks = std::min<int64_t>((threads + 255) / 256, 1 << 20);
+        hipLaunchKernelGGL(subsample_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint8_t *>(x->data),
+                           wsp + p.sub_off, n_planes, (int)sh->H, (int)sh->W, (int)shd.H, (int)shd.W, (int)sh->stride);
+        QE_LAUNCH_CHECK();
+        xs = *x;
+        xs.data = wsp + p.sub_off;
+        x = &xs;
+        sh = &shd;
     }
 
     PrepArgs pa;
