@@ -191,6 +191,7 @@ struct MfmaPlan {
     bool flat = false, wraw = false, ws = false, s2 = false, sm2 = false;
     bool expand = false;       // sub-8-bit activations are expanded to 8-bit codes in the workspace first
     size_t xe_off = 0;
+    bool flatg = false;        // flat 1x1 kernel for small planes (several whole images per tile)
     bool sub = false;          // strided 1x1: the sampled pixels are gathered into a dense tensor first
     size_t sub_off = 0;
     int PADW = 0;
@@ -234,7 +235,25 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits)
         const int rt = 224 / p.OW, seg = (sh->W + 15) / 16;
         if (64 * rt * seg <= 8 * MF_THREADS) { p.flat = true; p.s2 = true; }
     }
-    if (p.flat && p.s2) {
+    // 1x1 / stride 1 / no padding on 49..56-pixel planes (7x7 maps): the flat kernel's small-plane variant
+    // (conv_mfma_flatg_kernel).  QE_FLATG=0 leaves these layers on the halo kernel.
+    if (!p.flat && p.KK == 1 && sh->stride == 1 && sh->padding == 0 && x_bits == 8 && p.cfg == 0 && sh->IC >= 64 &&
+        (P + 7) / 8 == 7 && (int64_t)sh->N * sh->IC * P < (1ll << 32) &&
+        !(getenv("QE_FLATG") && atoi(getenv("QE_FLATG")) == 0)) {
+        const int nch = (sh->IC + 31) / 32;
+        p.flatg = true;
+        p.IWP = 56;                                   // slots per image (P rounded up to 8)
+        p.GI = std::max(1, std::min((int)sh->N, 224 / p.IWP));
+        p.NS = nch >= 4 ? 4 : 2;
+        p.lds = std::max((size_t)(32 * p.NS) * 224, (size_t)4 * 32 * 36 * 4) + (size_t)224 * 4;
+        p.TH = 1; p.ni = 7; p.niw = 7;
+        p.NCH = nch; p.NG = 2 * nch;
+        p.wraw = (w_bits == 8) && (sh->IC % 16) == 0;
+        p.wt_bytes = p.wraw ? 0 : (size_t)p.NG * p.OCP * 16;
+        p.IHT = 1;
+    }
+    if (p.flatg) {
+    } else if (p.flat && p.s2) {
         const int ntp = 224, rstr = 224;
         p.NS = 2;
         p.lds = std::max((size_t)64 * rstr, (size_t)4 * 32 * 36 * 4) + (size_t)ntp * 4;
@@ -284,7 +303,7 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits)
     // stride-2 layers +15 % (the warp-specialised kernel / bigger halo tiles win there).  Default: stride 1 and a
     // tile that is either 64 channels wide or a whole image; QE_SM2=1 forces it wherever it fits, QE_SM2=0 never.
     const int sm2_env = getenv("QE_SM2") ? atoi(getenv("QE_SM2")) : -1;
-    if (!p.flat && !p.smallic && p.KK == 9 && sh->KW == 3 && sh->KH == 3 && x_bits == 8 && p.cfg <= 1 && sm2_env != 0) {
+    if (!p.flat && !p.flatg && !p.smallic && p.KK == 9 && sh->KW == 3 && sh->KH == 3 && x_bits == 8 && p.cfg <= 1 && sm2_env != 0) {
         const int max_px = 32 * (p.cfg == 0 ? 8 : 16);
         int GI = 1;
         if (p.OH * p.OW <= max_px / 2) GI = std::max(1, std::min((int)sh->N, max_px / (p.OH * p.OW)));
@@ -314,7 +333,7 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits)
             if (!p.sm2) { p.GI = 1; p.TH = 0; p.NS = 1; }   // the halo plan below starts from scratch
         }
     }
-    if (p.flat || p.sm2) {
+    if (p.flat || p.flatg || p.sm2) {
     } else if (p.smallic) {
         // stem layout: K = (kh) x [kw 0..7][ic 0..3]; the whole (tiny) channel depth is one stage
         p.NCH = 1;
@@ -395,7 +414,7 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits)
             if (lds <= (size_t)MF_MAX_LDS) { p.ws = true; p.lds = lds; p.IWP = iwp; p.PADW = nopad ? 0 : sh->padding; }
         }
     }
-    if (p.flat && p.wraw) { p.total = 0; p.ok = true; return p; }
+    if ((p.flat || p.flatg) && p.wraw) { p.total = 0; p.ok = true; return p; }
     p.ep_off = align_up(p.wt_bytes, 256);
     p.ws_off = align_up(p.ep_off + (size_t)3 * p.OCP * sizeof(float), 256);
     p.total = align_up(p.ws_off + (size_t)p.OCP * (sh->KH + 1) * (sh->KW + 1) * sizeof(int), 256);
@@ -538,7 +557,7 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     pa.wt = reinterpret_cast<int8_t *>(wsp);
     pa.ep = reinterpret_cast<float *>(wsp + p.ep_off);
     pa.ws = reinterpret_cast<int *>(wsp + p.ws_off);
-    if (p.flat && p.wraw) {
+    if ((p.flat || p.flatg) && p.wraw) {
         // nothing to prepare: the kernel reads the packed tensor and builds its constants itself
     } else if (p.smallic)
         hipLaunchKernelGGL(conv_mfma_prep_smallic_kernel, dim3(p.OCP), dim3(64), 0, s, pa, (int)sh->KH, (int)sh->KW);
@@ -564,7 +583,11 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     a.n_pix_tiles = ((sh->N + p.GI - 1) / p.GI) * a.tiles_h;
     a.n_oc_tiles = p.OCP / p.MT;
     int64_t n_units = a.n_pix_tiles;             // what the XCD-aware block map distributes
-    if (p.flat) {
+    if (p.flatg) {
+        a.tiles_h = 1;                           // one tile = GI whole images
+        a.n_pix_tiles = (sh->N + p.GI - 1) / p.GI;
+        n_units = a.n_pix_tiles;
+    } else if (p.flat) {
         a.tiles_h = p.IHT;                       // pixel tiles per image
         a.n_pix_tiles = sh->N * a.tiles_h;
         n_units = a.n_pix_tiles;   // one pixel tile per workgroup: runs of several tiles with cross-tile
@@ -588,6 +611,11 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     const int64_t blocks = groups * 8 * a.n_oc_tiles;
     if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
     const bool x8 = x->n_bits == 8;
+    if (p.flatg) {
+        launch_mfma_flatg(a, p.NS, p.wraw, (unsigned)blocks, p.lds, s);
+        QE_LAUNCH_CHECK();
+        return QE_OK;
+    }
     if (p.flat) {
         launch_mfma_flat(a, p.cfg, p.niw, p.NS, p.wraw, p.s2, (unsigned)blocks, p.lds, s);
         QE_LAUNCH_CHECK();

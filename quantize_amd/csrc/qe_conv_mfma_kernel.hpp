@@ -1544,6 +1544,217 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// Flat 1x1 kernel for SMALL planes whose size is not a multiple of 4 (7x7 = 49 pixels: the last ResNet stage).
+// Same GEMM, operand roles, weight path and store patch as conv_mfma_flat_kernel; what differs is the tile:
+//   * a tile is GI whole images; image gi owns the pixel slots [gi * PS, gi * PS + P) of the LDS rows, PS = P rounded
+//     up to 8 (49 -> 56; 4 images = 224 slots = 7 MFMA column tiles; slots P..PS-1 are never stored);
+//   * a channel plane is P contiguous bytes at an arbitrary byte alignment (49 * k): it is fetched as 8-byte pieces
+//     with byte-unaligned global_load_dwordx2 (probed: tools/probe_unaligned.hip), the last piece ENDING at the plane's
+//     end and shifted down, so nothing is read past a plane; pieces land 8-byte aligned in LDS, which is all
+//     ds_read_b64_tr_b8 needs.  14 piece loads per thread and 128-channel stage instead of the halo kernel's 32
+//     unaligned dword loads + 8 byte transposes (its load issue alone was 38 % of a wave's life on 2048->512 @7x7);
+//   * output rows are P floats at 4-byte alignment: global_store_dwordx4 at dword alignment (probed), scalar stores
+//     for the last pixels of a plane.
+// a.IWP carries PS, a.GI the images per tile.  Host guarantees CK * GI * ceil(P / 8) <= 16 * 256 pieces per stage.
+// ---------------------------------------------------------------------------------------------
+template <int NIW, int NS, bool WRAW, int NP8>
+__global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flatg_kernel(const MfmaArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int WM = 4, MT = 128;
+    constexpr int NTP = 32 * NIW;               // pixel slots per tile
+    constexpr int RSTR = 32 * (NIW | 1);        // LDS row stride: odd multiple of 32 B
+    constexpr int CK = 32 * NS;
+    constexpr int GIM = 4;                      // image slots per tile the row map is built for
+    constexpr int UPI = CK * NP8;               // 8-byte pieces of one image per stage
+    constexpr int RPT = (UPI + MF_THREADS - 1) / MF_THREADS;   // piece rounds per thread (x GIM images each)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave;
+    const int col = lane & 31, h = lane >> 5;
+    const int P = a.H * a.W, PS = a.IWP, GI = a.GI;
+    const int tail_r = P - 8 * (NP8 - 1);       // valid bytes of the last piece (1..8; host checks)
+
+    int pt, ot;
+    block_to_tile(a, pt, ot);
+    if (pt >= a.n_pix_tiles) return;
+    const int n0 = pt * GI;
+
+    uint8_t *Xs = smem;
+    constexpr int XS_BYTES = (CK * RSTR > 4 * 32 * 36 * 4) ? CK * RSTR : 4 * 32 * 36 * 4;
+    int *sxp = reinterpret_cast<int *>(smem + XS_BYTES);
+
+    const int oc = ot * MT + wm * 32 + col;
+    const int occ = oc < a.OC ? oc : a.OC - 1;
+    const float sw = a.w_per_tensor ? a.w_scale[0] : a.w_scale[occ];
+    const float zwp = (a.w_per_tensor ? a.w_zero[0] : a.w_zero[occ]) - zero_shift(a.w_bits, a.w_sign);
+    const float alpha = a.x_scale[0] * sw;
+    const float bia = a.bias ? a.bias[occ] : 0.0f;
+    const float zxp = a.x_zero[0] - zero_shift(a.x_bits, a.x_sign);
+
+    // ---- staging (stage invariant): piece u = tid + 256 j <-> (channel c = u / NP8, piece k = u % NP8) of EVERY image
+    // of the tile, so the lanes of a load instruction read consecutive 8-byte pieces of consecutive channel planes
+    // (one contiguous span per image).  The last piece of a plane starts at P - 8 and is shifted down.
+    int pcl[RPT], plds[RPT];
+    uint32_t pgo[RPT];
+    bool ptail[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        const int u = tid + MF_THREADS * j;
+        const int c = u / NP8, kk = u - c * NP8;
+        const bool ok = u < UPI;
+        pcl[j] = ok ? c : 0;
+        ptail[j] = kk == NP8 - 1;
+        pgo[j] = (uint32_t)(ptail[j] ? P - 8 : 8 * kk);
+        plds[j] = ok ? c * RSTR + 8 * kk : -1;
+    }
+    const int tail_sh = 8 * (8 - tail_r);
+    const uint8_t *xg = a.x + (int64_t)n0 * a.IC * P;
+    const int64_t img_stride = (int64_t)a.IC * P;
+
+    const int NGR = (a.IC + 15) >> 4;
+    const uint8_t *w_lane = WRAW ? a.w_raw + (int64_t)occ * a.IC : nullptr;
+    const int8_t *wt_base = a.wt + (int64_t)(ot * MT + wm * 32) * 16;
+    const uint32_t wt_voff = (uint32_t)col * 16u;
+
+    v16i acc[NIW];
+#pragma unroll
+    for (int t = 0; t < NIW; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0;
+    }
+    int swacc = 0;
+    const int i16 = lane & 15;
+    const int tr_base = (16 * h + (i16 >> 1)) * RSTR + 16 * ((lane >> 4) & 1) + 8 * (i16 & 1);
+
+    uint2 d[RPT][GIM];
+    auto issue_x = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const int cg = s * CK + pcl[j];
+            const int cgc = cg < a.IC ? cg : a.IC - 1;
+            const uint32_t off = (uint32_t)cgc * (uint32_t)P + pgo[j];
+#pragma unroll
+            for (int gi = 0; gi < GIM; ++gi) {
+                const int gic = (gi < GI && n0 + gi < a.N) ? gi : 0;             // uniform
+                __builtin_memcpy(&d[j][gi], xg + gic * img_stride + off, 8);     // byte-unaligned global_load_dwordx2
+            }
+        }
+    };
+    issue_x(0);
+
+    const bool need_sx = __syncthreads_or((oc < a.OC && zwp != 0.0f) ? 1 : 0) != 0;
+    if (need_sx) {
+        for (int i = tid; i < NTP; i += MF_THREADS) sxp[i] = 0;
+        __syncthreads();
+    }
+
+    auto stage_x = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+#pragma unroll
+            for (int gi = 0; gi < GIM; ++gi) {
+                unsigned long long v = ((unsigned long long)d[j][gi].y << 32) | d[j][gi].x;
+                if (ptail[j]) v >>= tail_sh;                   // tail piece: its valid bytes come down to byte 0
+                v ^= 0x8080808080808080ull;
+                if (plds[j] >= 0 && gi < GI && n0 + gi < a.N) {
+                    *reinterpret_cast<unsigned long long *>(Xs + plds[j] + gi * PS) = v;
+                    if (need_sx && s * CK + pcl[j] < a.IC) {   // rare path (asymmetric weights)
+                        const int pb = plds[j] - pcl[j] * RSTR + gi * PS;
+                        for (int b = 0; b < 8; ++b) atomicAdd(&sxp[pb + b], (int)(int8_t)(v >> (8 * b)));
+                    }
+                }
+            }
+        }
+    };
+    auto stage = [&](int s, auto prefetch) __attribute__((always_inline)) {
+        v4i wf[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int icg = 2 * (s * NS + k) + h;
+            const int icgc = icg < NGR ? icg : NGR - 1;
+            v4i f;
+            if constexpr (WRAW) {
+                __builtin_memcpy(&f, w_lane + icgc * 16, 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f[j] ^= (int)0x80808080;
+            } else {
+                f = *reinterpret_cast<const v4i *>(wt_base + (int64_t)icgc * a.OCP * 16 + wt_voff);
+            }
+            if (icg >= NGR) f = v4i{0, 0, 0, 0};
+            wf[k] = f;
+        }
+        stage_x(s);
+        __syncthreads();
+        if constexpr (decltype(prefetch)::value) issue_x(s + 1);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) swacc = __builtin_amdgcn_sdot4(wf[k][j], 0x01010101, swacc, false);
+#pragma unroll
+            for (int t = 0; t < NIW; ++t) {
+                const uint8_t *src = Xs + tr_base + (k * 32) * RSTR + t * 32;
+                const v2i lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(src));
+                const v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(src + 8 * RSTR));
+                const v4i xf = {lo[0], lo[1], hi[0], hi[1]};
+                acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xf, wf[k], acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    };
+
+    const int n_stages = (a.IC + CK - 1) / CK;
+    for (int s = 0; s < n_stages - 1; ++s) stage(s, std::true_type{});
+    stage(n_stages - 1, std::false_type{});
+
+    // ---- epilogue: lane = output channel, 4 consecutive registers = 4 consecutive slots; per-wave LDS patch ----
+    const int sw_sum = swacc + __shfl_xor(swacc, 32);
+    const float cst = fmaf((float)a.IC * zxp, zwp, -zxp * (float)sw_sum);
+    float *patch = reinterpret_cast<float *>(smem) + wave * (32 * 36);
+    const int rrow = lane >> 3, rq = lane & 7;
+    const int row_oc = ot * MT + wm * 32;               // first output channel of this wave's strip
+#pragma unroll
+    for (int t = 0; t < NIW; ++t) {
+        const int q0 = t * 32;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float f = (float)acc[t][4 * gq + j] + cst;
+                if (need_sx) f = fmaf(-zwp, (float)sxp[q0 + 8 * gq + 4 * h + j], f);
+                v[j] = fmaf(alpha, f, bia);
+            }
+            *reinterpret_cast<float4 *>(patch + col * 36 + 8 * gq + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): same wave wrote and reads
+        // this lane's 4 slots of the tile: image gi, pixels p .. p+3 (PS % 4 == 0: never across images)
+        const int m = q0 + 4 * rq;
+        const int gi = m / PS, p = m - gi * PS;
+        const bool img_ok = gi < GI && n0 + gi < a.N;
+        float *orow = a.out + ((int64_t)(n0 + (img_ok ? gi : 0)) * a.OC + row_oc) * P + p;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 8 * i + rrow;
+            const float4 o4 = *reinterpret_cast<const float4 *>(patch + row * 36 + 4 * rq);
+            if (img_ok && row_oc + row < a.OC) {
+                float *dst = orow + (int64_t)row * P;
+                if (p + 4 <= P) {
+                    __builtin_memcpy(dst, &o4, 16);       // dword-aligned global_store_dwordx4
+                } else {
+                    if (p < P) dst[0] = o4.x;
+                    if (p + 1 < P) dst[1] = o4.y;
+                    if (p + 2 < P) dst[2] = o4.z;
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+}
+
 // launchers, one translation unit per wave layout (qe_conv_mfma_i*.hip)
 void launch_mfma_cfg0(const MfmaArgs &a, int niw, int ns, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_cfg1(const MfmaArgs &a, int niw, int ns, int KK, bool x8, unsigned blocks, size_t lds, hipStream_t s);
@@ -1551,6 +1762,7 @@ void launch_mfma_cfg2(const MfmaArgs &a, int niw, int ns, int KK, bool x8, unsig
 void launch_mfma_smallic(const MfmaArgs &a, int cfg, int niw, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_ws(const MfmaArgs &a, int niw, int split, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_sm2(const MfmaArgs &a, int wms, int split, unsigned blocks, size_t lds, hipStream_t s);
+void launch_mfma_flatg(const MfmaArgs &a, int ns, bool wraw, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_flat(const MfmaArgs &a, int cfg, int niw, int ns, bool wraw, bool s2, unsigned blocks, size_t lds, hipStream_t s);
 
 #define QE_MFMA_K(WM, WN, NIW, KKT, X8, NS) \

@@ -159,6 +159,8 @@ SWEEP_SHAPES = [
     (1, 64, 56, 56, 64, 3, 1, 1),    # 3x3 two-strip kernel, 14 column tiles over 4 pixel waves
     (2, 3, 40, 40, 64, 7, 2, 3),     # stem kernel, 64-channel workgroups with 14 column tiles
     (1, 4, 20, 24, 48, 5, 1, 2),     # stem kernel, 4 input channels, 5x5
+    (6, 160, 7, 7, 200, 1, 1, 0),    # small-plane flat kernel (49-pixel planes), partial image group and oc tile
+    (3, 64, 7, 8, 130, 1, 1, 0),     # small-plane flat kernel, 56-pixel planes (no tail shift)
 ]
 
 
@@ -252,7 +254,7 @@ def test_conv_error_messages(engine):
 
 @pytest.mark.parametrize("env", [{"QE_SM2": "0", "QE_WS": "1"}, {"QE_SM2": "0", "QE_WS": "1", "QE_WS_NOPAD": "1"},
                                  {"QE_SM2": "0", "QE_WS": "0"}, {"QE_SM2": "1"}, {"QE_FLAT_NIW": "4"}, {"QE_FLAT_NIW": "5"},
-                                 {"QE_FLAT_NIW": "7"}, {"QE_CHUNK_IMAGES": "0"}, {"QE_CHUNK_IMAGES": "1"}, {"QE_SUBSAMPLE": "0"}])
+                                 {"QE_FLAT_NIW": "7"}, {"QE_CHUNK_IMAGES": "0"}, {"QE_CHUNK_IMAGES": "1"}, {"QE_SUBSAMPLE": "0"}, {"QE_FLATG": "0"}])
 def test_kernel_variants_forced_by_env(engine, env):
     """The tuning knobs select other kernel variants (two-strip / warp-specialised (padded, unpadded LDS rows) /
     single-role 3x3, flat tile widths, block maps); every variant must meet the same parity bar."""
@@ -264,7 +266,7 @@ def test_kernel_variants_forced_by_env(engine, env):
         for shp in [(2, 256, 14, 14, 256, 3, 1, 1), (3, 128, 28, 28, 128, 3, 1, 1), (4, 160, 7, 7, 130, 3, 1, 1),
                     (2, 128, 14, 14, 192, 3, 2, 1), (2, 256, 28, 28, 160, 1, 1, 0), (5, 64, 7, 7, 48, 3, 1, 1),
                     (9, 96, 30, 30, 130, 3, 2, 1), (2, 128, 56, 56, 160, 1, 2, 0), (3, 256, 14, 14, 140, 1, 2, 0),
-                    (2, 64, 15, 13, 40, 1, 3, 0)]:
+                    (2, 64, 15, 13, 40, 1, 3, 0), (9, 512, 7, 7, 256, 1, 1, 0), (5, 2048, 7, 7, 130, 1, 1, 0)]:
             for zeros in (False, True):
                 case = _random_case(rng, *shp, 8, 1, 8, 0 if zeros else 1, w_pc=True, a_pc=False, zeros=zeros, bias=True)
                 y, o32, o64 = _run_case(engine, case, via_capi=True)
