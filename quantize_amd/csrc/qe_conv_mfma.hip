@@ -443,8 +443,13 @@ static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits, int w_bits)
     // Strided 1x1 (the ResNet downsample branches): gather the sampled pixels once (read every other row, write 1/s^2 of
     // the bytes) and run the stride-1 kernels on the dense tensor, instead of staging 2-4x the needed bytes in every
     // one of the OC/128 workgroups that share a pixel tile.  QE_SUBSAMPLE=0 keeps the in-kernel strided staging.
-    const bool sub = sh->KH == 1 && sh->KW == 1 && sh->stride > 1 && sh->padding == 0 && xb == 8 &&
-                     !(getenv("QE_SUBSAMPLE") && atoi(getenv("QE_SUBSAMPLE")) == 0);
+    // Measured (rocprofv3, in the stack): 512->1024 @28->14 187 -> 137 us, 1024->2048 @14->7 143 -> 109 us; on
+    // 256->512 @56->28 the gather (93 us) costs more than it saves, so output planes above 256 pixels keep the flat
+    // kernel's in-kernel stride-2 staging.  QE_SUBSAMPLE=1 forces the gather, =0 disables it.
+    const int sub_env = getenv("QE_SUBSAMPLE") ? atoi(getenv("QE_SUBSAMPLE")) : -1;
+    const int p_out = ((sh->H - 1) / std::max(1, (int)sh->stride) + 1) * ((sh->W - 1) / std::max(1, (int)sh->stride) + 1);
+    const bool sub = sh->KH == 1 && sh->KW == 1 && sh->stride > 1 && sh->padding == 0 && xb == 8 && sub_env != 0 &&
+                     (sub_env > 0 || p_out <= 256);
     const qe_conv_shape ds = dense_shape(sh);
     MfmaPlan p = make_plan8(sub ? &ds : sh, xb, w_bits);
     if (p.ok && sub) {
@@ -462,36 +467,80 @@ static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits, int w_bits)
     return p;
 }
 
-// out[r][ow] = in[r_in][ow * s] for the rows r = (n*IC + c)*OH + oh: one thread per 4 output bytes.
+// out[r][ow] = in[r_in][ow * s] for the rows r = (n*IC + c)*OH + oh.
+// WIDE (stride 2, W % 4 == 0, W >= 16): one thread per 8 output bytes = one 16-byte load (clamped to end at the row's
+// end and rotated back by whole dwords, so nothing is read past a row), two v_perm, one 8-byte store.
+// otherwise: one thread per 4 output bytes, byte gathers.
+template <bool WIDE>
 __global__ __launch_bounds__(256) void subsample_kernel(const uint8_t *__restrict__ x, uint8_t *__restrict__ y, int64_t n_planes,
                                                         int H, int W, int OH, int OW, int s)
 {
-    const int nq = (OW + 3) >> 2;
-    const int64_t total = n_planes * OH * nq;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / nq;
-        const int q = (int)(i - r * nq);
-        const int64_t plane = r / OH;
-        const int oh = (int)(r - plane * OH);
-        const uint8_t *src = x + (plane * H + (int64_t)oh * s) * W;
-        const int ow0 = 4 * q;
-        uint32_t v = 0;
-        if (s == 2 && 2 * ow0 + 8 <= W) {
-            uint32_t d[2];
-            __builtin_memcpy(d, src + 2 * ow0, 8);                   // 8 input bytes, keep the even ones
-            v = __builtin_amdgcn_perm(d[1], d[0], 0x06040200u);
-        } else {
+    constexpr int OPT = WIDE ? 8 : 4;            // output bytes per unit
+    constexpr int UPT = 4;                       // units per thread, all loads issued before the first store
+    const int nq = (OW + OPT - 1) / OPT;
+    const int U = OH * nq;                       // units of one plane
+    const int ppb = U >= 256 * UPT ? 1 : (256 * UPT) / U;   // planes per workgroup (32-bit index math only)
+    for (int t0 = threadIdx.x; t0 < ppb * U; t0 += 256 * UPT) {
+        uint4 d[UPT];
+        uint32_t g[UPT];
+        uint8_t *dst[UPT];
+        int ow0[UPT], rot[UPT];
+        bool live[UPT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (ow0 + j < OW) v |= (uint32_t)src[(int64_t)(ow0 + j) * s] << (8 * j);
+        for (int k = 0; k < UPT; ++k) {
+            const int t = t0 + 256 * k;
+            const int pl = t / U, u = t - pl * U;
+            const int64_t plane = (int64_t)blockIdx.x * ppb + pl;
+            live[k] = t < ppb * U && plane < n_planes;
+            const int64_t pc = live[k] ? plane : 0;
+            const int oh = u / nq, q = u - oh * nq;
+            const uint8_t *src = x + (pc * H + (int64_t)oh * s) * W;
+            ow0[k] = OPT * q;
+            dst[k] = y + (pc * OH + oh) * OW + ow0[k];
+            if constexpr (WIDE) {
+                const int iw = 2 * ow0[k];                                // first input column of this unit
+                const int iwc = iw < W - 16 ? iw : W - 16;                // 16 bytes that end inside the row
+                __builtin_memcpy(&d[k], src + iwc, 16);
+                rot[k] = (iw - iwc) >> 2;                                 // whole dwords (W % 4 == 0)
+            } else {
+                uint32_t v = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = ow0[k] + j < OW ? ow0[k] + j : OW - 1;  // clamped: always a valid byte of the row
+                    v |= (uint32_t)src[(int64_t)c * s] << (8 * j);
+                }
+                g[k] = v;
+            }
         }
-        uint8_t *dst = y + r * OW + ow0;
-        if (ow0 + 4 <= OW && (reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
-            *reinterpret_cast<uint32_t *>(dst) = v;
-        } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (ow0 + j < OW) dst[j] = (uint8_t)(v >> (8 * j));
+        for (int k = 0; k < UPT; ++k) {
+            if (!live[k]) continue;
+            if constexpr (WIDE) {
+                const uint4 dd = d[k];
+                const int r = rot[k];
+                const uint32_t d0 = r == 0 ? dd.x : (r == 1 ? dd.y : (r == 2 ? dd.z : dd.w));
+                const uint32_t d1 = r == 0 ? dd.y : (r == 1 ? dd.z : (r == 2 ? dd.w : 0u));
+                const uint32_t d2 = r == 0 ? dd.z : (r == 1 ? dd.w : 0u);
+                const uint32_t d3 = r == 0 ? dd.w : 0u;
+                const uint32_t lo = __builtin_amdgcn_perm(d1, d0, 0x06040200u);   // even bytes of d0, d1
+                const uint32_t hi = __builtin_amdgcn_perm(d3, d2, 0x06040200u);
+                if (ow0[k] + 8 <= OW && (reinterpret_cast<uintptr_t>(dst[k]) & 3) == 0) {
+                    const uint2 o = make_uint2(lo, hi);
+                    __builtin_memcpy(dst[k], &o, 8);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (ow0[k] + j < OW) dst[k][j] = (uint8_t)((j < 4 ? lo : hi) >> (8 * (j & 3)));
+                }
+            } else {
+                if (ow0[k] + 4 <= OW && (reinterpret_cast<uintptr_t>(dst[k]) & 3) == 0) {
+                    *reinterpret_cast<uint32_t *>(dst[k]) = g[k];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (ow0[k] + j < OW) dst[k][j] = (uint8_t)(g[k] >> (8 * j));
+                }
+            }
         }
     }
 }
@@ -539,10 +588,18 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     if (p.sub) {
         shd = dense_shape(sh);
         const int64_t n_planes = (int64_t)sh->N * sh->IC;
-        const int64_t threads = n_planes * shd.H * ((shd.W + 3) / 4);
-        const int64_t blocks = std::min<int64_t>((threads + 255) / 256, 1 << 20);
-        hipLaunchKernelGGL(subsample_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint8_t *>(x->data),
-                           wsp + p.sub_off, n_planes, (int)sh->H, (int)sh->W, (int)shd.H, (int)shd.W, (int)sh->stride);
+        const bool wide = sh->stride == 2 && (sh->W % 4) == 0 && sh->W >= 16;
+        const int opt = wide ? 8 : 4;
+        const int units = shd.H * ((shd.W + opt - 1) / opt);
+        const int ppb = units >= 1024 ? 1 : 1024 / units;   // 4 units per thread
+        const int64_t blocks = (n_planes + ppb - 1) / ppb;
+        if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
+        if (wide)
+            hipLaunchKernelGGL(subsample_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint8_t *>(x->data),
+                               wsp + p.sub_off, n_planes, (int)sh->H, (int)sh->W, (int)shd.H, (int)shd.W, (int)sh->stride);
+        else
+            hipLaunchKernelGGL(subsample_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint8_t *>(x->data),
+                               wsp + p.sub_off, n_planes, (int)sh->H, (int)sh->W, (int)shd.H, (int)shd.W, (int)sh->stride);
         QE_LAUNCH_CHECK();
         xs = *x;
         xs.data = wsp + p.sub_off;
