@@ -295,7 +295,7 @@ def main():
                        "layers": n_launch, "kernel_paths": {"mfma": sum(L.path for L in layers),
                                                             "generic": sum(1 - L.path for L in layers)}},
             "roofline": {"bound": "hbm",
-                         "kernel": "conv_mfma_{flat,sm2,ws,smallic,}_kernel: 53 launches per step, one per layer (avg includes the 20 weight-prep launches, 3 us per layer)",
+                         "kernel": "conv_mfma_{flat,sm2,ws,smallic,}_kernel: flat/flatg/sm2/halo/ws/stem, 53 launches per step, one per layer (the event span also holds the 15 weight-prep and 2 gather launches, 3 us per layer)",
                          "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": traffic,

@@ -22,7 +22,10 @@ for idx in [int(v) for v in sys.argv[1:]]:
     L.qe_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     layer.run(st); torch.cuda.synchronize()
-    buf.zero_(); layer.run(st); torch.cuda.synchronize()
+    buf.zero_()
+    if os.environ.get("QE_STAMP_COLD"):   # inputs from HBM, as inside the stack
+        torch.empty(1 << 28, dtype=torch.float32, device=dev).fill_(1.0)
+    layer.run(st); torch.cuda.synchronize()
     dall = buf.view(-1, 10)
     groups = [("all waves", dall)]
     if os.environ.get("QE_STAMP_WS"):   # warp-specialised kernel: 8 waves per block, 0-3 consumers, 4-7 producers
