@@ -11,7 +11,8 @@ main = [i for i, r in enumerate(rows) if "conv_mfma" in r["Kernel_Name"] and "pr
 assert len(main) % 53 == 0, len(main)
 first = main[-53]
 # include a prep kernel that belongs to the first layer of the step
-while first > 0 and "prep" in rows[first - 1]["Kernel_Name"]:
+while first > 0 and ("prep" in rows[first - 1]["Kernel_Name"] or "subsample" in rows[first - 1]["Kernel_Name"]
+                     or "tunpack" in rows[first - 1]["Kernel_Name"]):
     first -= 1
 last = main[-1]
 iso = json.load(open(sys.argv[2])) if len(sys.argv) > 2 else None
@@ -24,7 +25,7 @@ for r in rows[first:last + 1]:
     short = name.split("(")[0].replace("void qe::", "")[:60]
     gap = (s - t_prev) / 1e3 if t_prev is not None else 0.0
     dur = (e - s) / 1e3
-    is_prep = "prep" in name
+    is_prep = "conv_mfma" not in name or "prep" in name   # weight prep, strided gather, code expansion
     if not is_prep:
         layer += 1
         tot_main += dur
@@ -34,8 +35,8 @@ for r in rows[first:last + 1]:
     extra = ""
     if iso and not is_prep:
         extra = "  isolated %.1f us  %s" % (iso[layer]["ms"] * 1e3, iso[layer]["shape"])
-    print("%-5s gap %6.1f us  dur %7.1f us  %s%s" % ("prep" if is_prep else "L%d" % layer, gap, dur, short, extra))
+    print("%-5s gap %6.1f us  dur %7.1f us  %s%s" % ("aux" if is_prep else "L%d" % layer, gap, dur, short, extra))
     t_prev = e
-print("main %.3f ms, prep %.3f ms, gaps %.3f ms, span %.3f ms" % (
+print("main %.3f ms, aux (prep/gather) %.3f ms, gaps %.3f ms, span %.3f ms" % (
     tot_main / 1e3, tot_prep / 1e3, tot_gap / 1e3,
     (int(rows[last]["End_Timestamp"]) - int(rows[first]["Start_Timestamp"])) / 1e6))
