@@ -1562,7 +1562,7 @@ template <int NIW, int NS, bool WRAW, int NP8>
 __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flatg_kernel(const MfmaArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr int WM = 4, MT = 128;
+    constexpr int MT = 128;                     // 4 waves x 32 output channels
     constexpr int NTP = 32 * NIW;               // pixel slots per tile
     constexpr int RSTR = 32 * (NIW | 1);        // LDS row stride: odd multiple of 32 B
     constexpr int CK = 32 * NS;
