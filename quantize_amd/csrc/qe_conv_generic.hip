@@ -13,8 +13,9 @@
 //
 // Machine mapping (nothing like the reference's one-thread-per-output kernel):
 //   workgroup (256 threads) = one image, PT consecutive output pixels (64 or 256)
-//   x OCB = 16*(256/PT) output channels; each thread owns ONE pixel and 16 output
-//   channels in registers.  Per chunk of CI input channels the dequantised input
+//   x OCB = 16*(1024/PT) output channels; each thread owns 4 consecutive pixels and 16 output
+//   channels in registers (one LDS weight vector feeds 4 x 16 FMAs: the one-pixel version spent
+//   5 LDS reads per 16 FMAs and ran at 5-13 TFLOP/s).  Per chunk of CI input channels the dequantised input
 //   band (all rows the tile touches, full padded width) and the dequantised
 //   weights [ci][tap][oc] are staged in LDS once and reused by all taps / all
 //   threads: input reads are one conflict-free ds_read_b32 per tap, weights are
@@ -56,13 +57,15 @@ __device__ __forceinline__ int unpack_elem(const uint8_t *__restrict__ p, int64_
 
 constexpr int GC_THREADS = 256;
 constexpr int GC_OCT = 16;  // output channels per thread
+constexpr int GC_PXT = 4;   // consecutive output pixels per thread: a weight vector read from LDS feeds 4 x 16 FMAs
 
 template <bool PACKED_IN>
 __global__ __launch_bounds__(GC_THREADS) void conv_generic_kernel(const GenericConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int KK = a.KH * a.KW;
-    const int OCB = GC_OCT * (GC_THREADS / a.PT);
+    const int TPX = a.PT / GC_PXT;                   // threads along the pixels
+    const int OCB = GC_OCT * (GC_THREADS / TPX);
     float *Xs = smem;                                          // [CI][IHT_max][IWT]
     float *Ws = smem + (size_t)a.CI * a.IHT_max * a.IWT;       // [CI][KK][OCB]
     // keep Ws 16-byte aligned for the float4 reads
@@ -82,21 +85,28 @@ __global__ __launch_bounds__(GC_THREADS) void conv_generic_kernel(const GenericC
     const int ih0 = oh_first * a.stride - a.padding;
     const int IHT = (oh_last - oh_first) * a.stride + a.KH;  // <= IHT_max
 
-    const int px = tid % a.PT;
-    const int ocg = tid / a.PT;
-    const int p = p0 + px;
-    const bool p_valid = p < OHW;
-    const int oh = p_valid ? p / a.OW : oh_first;
-    const int ow = p_valid ? p % a.OW : 0;
-    const int xrow0 = (oh - oh_first) * a.stride;  // + kh
-    const int xcol0 = ow * a.stride;               // + kw   (LDS column = iw + padding)
+    const int pxt = tid % TPX;
+    const int ocg = tid / TPX;
+    int pj[GC_PXT], xoff[GC_PXT];
+    bool pv[GC_PXT];
+#pragma unroll
+    for (int j = 0; j < GC_PXT; ++j) {
+        const int p = p0 + GC_PXT * pxt + j;
+        pv[j] = p < OHW;
+        const int oh = pv[j] ? p / a.OW : oh_first;
+        const int ow = pv[j] ? p % a.OW : 0;
+        pj[j] = p;
+        xoff[j] = ((oh - oh_first) * a.stride) * a.IWT + ow * a.stride;   // + kh * IWT + kw (LDS column = iw + padding)
+    }
     const int oc0 = ocb * OCB + ocg * GC_OCT;
 
-    float acc[GC_OCT];
+    float acc[GC_PXT][GC_OCT];
 #pragma unroll
     for (int i = 0; i < GC_OCT; ++i) {
         const int oc = oc0 + i;
-        acc[i] = (a.bias != nullptr && oc < a.OC) ? a.bias[oc] : 0.0f;  // quantconv2d.cu:92
+        const float b = (a.bias != nullptr && oc < a.OC) ? a.bias[oc] : 0.0f;  // quantconv2d.cu:92
+#pragma unroll
+        for (int j = 0; j < GC_PXT; ++j) acc[j][i] = b;
     }
 
     const int64_t x_img = (int64_t)n * a.IC * a.H * a.W;
@@ -148,19 +158,24 @@ __global__ __launch_bounds__(GC_THREADS) void conv_generic_kernel(const GenericC
 
         // ---- accumulate: ic -> kh -> kw, one fmaf per tap (quantconv2d.cu:95-137) --------
         for (int ci = 0; ci < cn; ++ci) {
-            const float *xrow = Xs + (ci * a.IHT_max + xrow0) * a.IWT + xcol0;
+            const float *xch = Xs + (ci * a.IHT_max) * a.IWT;
             const float *wrow = Ws + (ci * KK) * OCB + ocg * GC_OCT;
             for (int kh = 0; kh < a.KH; ++kh) {
                 for (int kw = 0; kw < a.KW; ++kw) {
-                    const float xv = xrow[kh * a.IWT + kw];
+                    float xv[GC_PXT];
+#pragma unroll
+                    for (int j = 0; j < GC_PXT; ++j) xv[j] = xch[xoff[j] + kh * a.IWT + kw];
                     const float4 *w4 = reinterpret_cast<const float4 *>(wrow + (kh * a.KW + kw) * OCB);
 #pragma unroll
-                    for (int j = 0; j < GC_OCT / 4; ++j) {
-                        const float4 wv = w4[j];
-                        acc[4 * j + 0] = fmaf(xv, wv.x, acc[4 * j + 0]);
-                        acc[4 * j + 1] = fmaf(xv, wv.y, acc[4 * j + 1]);
-                        acc[4 * j + 2] = fmaf(xv, wv.z, acc[4 * j + 2]);
-                        acc[4 * j + 3] = fmaf(xv, wv.w, acc[4 * j + 3]);
+                    for (int q = 0; q < GC_OCT / 4; ++q) {
+                        const float4 wv = w4[q];
+#pragma unroll
+                        for (int j = 0; j < GC_PXT; ++j) {
+                            acc[j][4 * q + 0] = fmaf(xv[j], wv.x, acc[j][4 * q + 0]);
+                            acc[j][4 * q + 1] = fmaf(xv[j], wv.y, acc[j][4 * q + 1]);
+                            acc[j][4 * q + 2] = fmaf(xv[j], wv.z, acc[j][4 * q + 2]);
+                            acc[j][4 * q + 3] = fmaf(xv[j], wv.w, acc[j][4 * q + 3]);
+                        }
                     }
                 }
             }
@@ -168,12 +183,14 @@ __global__ __launch_bounds__(GC_THREADS) void conv_generic_kernel(const GenericC
         __syncthreads();
     }
 
-    if (p_valid) {
-        float *o = a.out + ((int64_t)n * a.OC) * OHW + p;
+#pragma unroll
+    for (int j = 0; j < GC_PXT; ++j) {
+        if (!pv[j]) continue;
+        float *o = a.out + ((int64_t)n * a.OC) * OHW + pj[j];
 #pragma unroll
         for (int i = 0; i < GC_OCT; ++i) {
             const int oc = oc0 + i;
-            if (oc < a.OC) o[(int64_t)oc * OHW] = acc[i];  // quantconv2d.cu:140
+            if (oc < a.OC) o[(int64_t)oc * OHW] = acc[j][i];  // quantconv2d.cu:140
         }
     }
 }
@@ -200,7 +217,7 @@ int launch_conv_generic(bool packed_in, const void *x, const qe_qparam *xq, cons
 
     const int OHW = a.OH * a.OW;
     a.PT = (OHW <= 64) ? 64 : 256;
-    const int OCB = GC_OCT * (GC_THREADS / a.PT);
+    const int OCB = GC_OCT * (GC_THREADS / (a.PT / GC_PXT));
     a.IWT = a.W + 2 * a.padding;
     const int rows_max = min(a.OH, (a.PT - 1) / a.OW + 2);
     a.IHT_max = (rows_max - 1) * a.stride + a.KH;
