@@ -167,7 +167,7 @@ def main():
             L.run(sp)
 
     def tail():
-        feats = last.out.mean(dim=(2, 3))     # global average pool (a rocBLAS gemv formulation measured 5x slower)
+        feats = capi.global_avgpool(last.out)   # on the current stream; torch's mean(dim=(2,3)) takes 70 us here (1.5 TB/s)
         logits = feats @ fc_w.t()
         logits = qdist.gather_logits(logits) if world > 1 else logits
         return logits.argmax(dim=1)

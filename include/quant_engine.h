@@ -168,6 +168,12 @@ int qe_quantlinear_float_input(const float *x, const qe_qparam *w, const float *
 /* 0 = order-preserving fp32 kernel, 1 = int8 MFMA GEMM (8-bit x 8-bit operands, K % 64 == 0, 16-byte aligned streams). */
 int qe_quantlinear_path(const qe_qparam *x, const qe_qparam *w, int64_t B, int32_t K, int32_t O);
 
+/* ---- auxiliary (no counterpart in the reference's extension) ---------------------------------
+ * Global average pool of an fp32 NCHW tensor: out[plane] = mean(x[plane][0..P)) for n_planes = N*C planes of P
+ * contiguous floats.  The reference's models do this in PyTorch (torchvision ResNet: AdaptiveAvgPool2d); bench.py's
+ * top-1 tail uses this entry point because torch's reduction reads the (256,2048,7,7) conv output at 1.5 TB/s.     */
+int qe_global_avgpool(const float *x, int64_t n_planes, int32_t P, float *out, qe_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

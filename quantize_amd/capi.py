@@ -19,7 +19,7 @@ DTYPES = {"uint8": 0, "int8": 1, "int16": 2, "int32": 3, "int64": 4,
 SYMBOLS = ["qe_error_string", "qe_last_hip_error", "qe_version", "qe_target_arch", "qe_packed_nbytes",
            "qe_tpack", "qe_tunpack", "qe_quantconv2d_workspace_bytes", "qe_quantconv2d",
            "qe_quantconv2d_float_input", "qe_quantconv2d_path", "qe_quantlinear", "qe_quantlinear_float_input",
-           "qe_quantlinear_path"]
+           "qe_quantlinear_path", "qe_global_avgpool"]
 
 
 class QeConvShape(ctypes.Structure):
@@ -71,6 +71,8 @@ def lib():
     L.qe_quantlinear_float_input.argtypes = [vp, ctypes.POINTER(QeQParam), vp, i64, i32, i32, vp, vp]
     L.qe_quantlinear_path.restype = i32
     L.qe_quantlinear_path.argtypes = [ctypes.POINTER(QeQParam), ctypes.POINTER(QeQParam), i64, i32, i32]
+    L.qe_global_avgpool.restype = i32
+    L.qe_global_avgpool.argtypes = [vp, i64, i32, vp, vp]
     _lib = L
     return L
 
@@ -193,4 +195,15 @@ def quantlinear_float_input(x, wq, bias, O, out=None, stream=None):
         out = torch.empty((B, O), dtype=torch.float32, device=x.device)
     check(lib().qe_quantlinear_float_input(x.data_ptr(), ctypes.byref(wq), None if bias is None else bias.data_ptr(),
                                            int(B), int(K), int(O), out.data_ptr(), _stream(stream)))
+    return out
+
+
+def global_avgpool(x, out=None, stream=None):
+    """mean over the last two dims of a contiguous fp32 NCHW tensor -> (N, C)."""
+    import torch
+    assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and x.dim() == 4
+    N, C, H, W = x.shape
+    if out is None:
+        out = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    check(lib().qe_global_avgpool(x.data_ptr(), N * C, H * W, out.data_ptr(), _stream(stream)))
     return out

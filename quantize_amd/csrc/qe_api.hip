@@ -91,3 +91,56 @@ extern "C" int qe_quantconv2d_float_input(const float *x, const qe_qparam *w, co
     if (x == nullptr || out == nullptr) return QE_ERR_ARG;
     return launch_conv_generic(false, x, nullptr, w, bias, shape, out, static_cast<hipStream_t>(stream));
 }
+
+// ---------------------------------------------------------------------------------------------
+// Global average pool (bench.py's top-1 tail): a workgroup copies 64 planes (64 * P contiguous floats) into LDS with
+// coalesced 16-byte loads, then 4 threads per plane add up a quarter each (P is small: 49 for ResNet-50) and the
+// quarters are combined with two shuffles.  HBM-bound: 103 MB for (256, 2048, 7, 7).
+// ---------------------------------------------------------------------------------------------
+namespace qe {
+constexpr int AP_PLANES = 64;
+__global__ __launch_bounds__(256) void global_avgpool_kernel(const float *__restrict__ x, float *__restrict__ out,
+                                                             int64_t n_planes, int P)
+{
+    extern __shared__ __attribute__((aligned(16))) float sp[];
+    const int64_t plane0 = (int64_t)blockIdx.x * AP_PLANES;
+    const int np = (int)((n_planes - plane0) < AP_PLANES ? (n_planes - plane0) : AP_PLANES);
+    const int nf = np * P;
+    const float *src = x + plane0 * P;
+    const bool al = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+    if (al) {
+        for (int i = threadIdx.x * 4; i < nf; i += 256 * 4) {
+            if (i + 4 <= nf) *reinterpret_cast<float4 *>(sp + i) = *reinterpret_cast<const float4 *>(src + i);
+            else for (int j = i; j < nf; ++j) sp[j] = src[j];
+        }
+    } else {
+        for (int i = threadIdx.x; i < nf; i += 256) sp[i] = src[i];
+    }
+    __syncthreads();
+    const int pl = threadIdx.x >> 2, part = threadIdx.x & 3;
+    float sum = 0.0f;
+    if (pl < np) {
+        const int per = (P + 3) >> 2;
+        const int lo = part * per, hi = (lo + per < P) ? lo + per : P;
+        for (int i = lo; i < hi; ++i) sum += sp[pl * P + i];
+    }
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    if (pl < np && part == 0) out[plane0 + pl] = sum / (float)P;
+}
+}  // namespace qe
+
+extern "C" int qe_global_avgpool(const float *x, int64_t n_planes, int32_t P, float *out, qe_stream_t stream)
+{
+    using namespace qe;
+    if (n_planes < 0 || P <= 0) return QE_ERR_ARG;
+    if (n_planes == 0) return QE_OK;
+    if (x == nullptr || out == nullptr) return QE_ERR_ARG;
+    if ((size_t)AP_PLANES * P * sizeof(float) > 60 * 1024) return QE_ERR_UNSUPPORTED;   // planes of at most 240 pixels
+    const int64_t blocks = (n_planes + AP_PLANES - 1) / AP_PLANES;
+    if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(global_avgpool_kernel, dim3((unsigned)blocks), dim3(256), (size_t)AP_PLANES * P * sizeof(float),
+                       static_cast<hipStream_t>(stream), x, out, n_planes, (int)P);
+    QE_LAUNCH_CHECK();
+    return QE_OK;
+}

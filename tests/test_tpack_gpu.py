@@ -153,3 +153,16 @@ def test_full_size_roundtrip_and_checksum(engine):
         ref, _ = oracle.tpack(seg.astype(np.float32), 3, False)
         got = p[start * 3 // 8: start * 3 // 8 + ref.size].cpu().numpy()
         assert np.array_equal(got, ref), start
+
+
+def test_global_avgpool_matches_torch():
+    """Auxiliary entry point used by bench.py's top-1 tail."""
+    from quantize_amd import capi
+    g = torch.Generator(device=DEV)
+    g.manual_seed(5)
+    for shape in [(5, 37, 7, 7), (3, 8, 14, 14), (2, 3, 1, 1), (256, 2048, 7, 7), (1, 130, 5, 3)]:
+        x = torch.randn(shape, generator=g, device=DEV)
+        y = capi.global_avgpool(x)
+        ref = x.double().mean(dim=(2, 3))
+        assert tuple(y.shape) == shape[:2]
+        assert float((y.double() - ref).abs().max()) <= 1e-6
