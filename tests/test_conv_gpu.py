@@ -301,3 +301,17 @@ def test_sub8_activation_paths(engine, expand):
             os.environ.pop("QE_EXPAND", None)
         else:
             os.environ["QE_EXPAND"] = old
+
+
+def test_4bit_weights_on_flat_kernels(engine):
+    """4-bit weights on the 1x1 kernels (through the prepared fragment table): signed and unsigned codes, zero points,
+    with 8-bit and expanded 4-bit activations."""
+    rng = np.random.RandomState(41)
+    for shp in [(2, 64, 14, 14, 64, 1, 1, 0), (2, 160, 14, 14, 200, 1, 1, 0), (6, 160, 7, 7, 200, 1, 1, 0),
+                (1, 16, 8, 8, 2, 1, 1, 0), (2, 128, 28, 28, 130, 1, 1, 0), (2, 96, 28, 28, 130, 1, 2, 0)]:
+        for (wb, wsgn, ab, asgn) in [(4, 1, 8, 1), (4, 0, 8, 0), (4, 1, 4, 1)]:
+            for zeros in (False, True):
+                case = _random_case(rng, *shp, wb, wsgn, ab, asgn, w_pc=True, a_pc=False, zeros=zeros, bias=True)
+                y, o32, o64 = _run_case(engine, case, via_capi=True)
+                assert case["path"] == 1
+                _assert_conv_close(y, o64, o32, "w4 %s %s zeros=%s" % (shp, (wb, wsgn, ab, asgn), zeros))
