@@ -668,6 +668,14 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     const int64_t blocks = groups * 8 * a.n_oc_tiles;
     if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
     const bool x8 = x->n_bits == 8;
+    // LDS room for the epilogue's copy of the tile's S_w prefix rows (asymmetric activations; stage_ptab)
+    size_t lds_e = p.lds;
+    a.ptab_off = 0;
+    if (!p.flat && !p.flatg && !p.ws) {
+        const size_t tab = (size_t)p.MT * (sh->KH + 1) * (sh->KW + 1) * sizeof(int);
+        const size_t off = align_up(p.lds, 16);
+        if (off + tab <= (size_t)(p.sm2 ? MF_MAX_LDS_SM2 : MF_MAX_LDS)) { a.ptab_off = (int)off; lds_e = off + tab; }
+    }
     if (p.flatg) {
         launch_mfma_flatg(a, p.NS, p.wraw, (unsigned)blocks, p.lds, s);
         QE_LAUNCH_CHECK();
@@ -681,7 +689,7 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     if (p.sm2) {
         const int units = p.GI * p.IHT * ((sh->W + 3) / 4);
         const int split = units <= 64 ? 4 : (units <= 128 ? 2 : 1);   // channel slices of the staging threads
-        launch_mfma_sm2(a, p.cfg == 0 ? 2 : 1, split, (unsigned)blocks, p.lds, s);
+        launch_mfma_sm2(a, p.cfg == 0 ? 2 : 1, split, (unsigned)blocks, lds_e, s);
         QE_LAUNCH_CHECK();
         return QE_OK;
     }
@@ -695,14 +703,14 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
         return QE_OK;
     }
     if (p.smallic) {
-        launch_mfma_smallic(a, p.cfg, p.niw, (unsigned)blocks, p.lds, s);
+        launch_mfma_smallic(a, p.cfg, p.niw, (unsigned)blocks, lds_e, s);
         QE_LAUNCH_CHECK();
         return QE_OK;
     }
     switch (p.cfg) {
-        case 0: launch_mfma_cfg0(a, p.niw, p.NS, p.KK, x8, (unsigned)blocks, p.lds, s); break;
-        case 1: launch_mfma_cfg1(a, p.niw, p.NS, p.KK, x8, (unsigned)blocks, p.lds, s); break;
-        default: launch_mfma_cfg2(a, p.niw, p.NS, p.KK, x8, (unsigned)blocks, p.lds, s); break;
+        case 0: launch_mfma_cfg0(a, p.niw, p.NS, p.KK, x8, (unsigned)blocks, lds_e, s); break;
+        case 1: launch_mfma_cfg1(a, p.niw, p.NS, p.KK, x8, (unsigned)blocks, lds_e, s); break;
+        default: launch_mfma_cfg2(a, p.niw, p.NS, p.KK, x8, (unsigned)blocks, lds_e, s); break;
     }
     QE_LAUNCH_CHECK();
     return QE_OK;

@@ -34,6 +34,7 @@ struct MfmaArgs {
     int GI;                    // whole images per pixel tile (> 1 only for small feature maps, TH == OH)
     int PADW;                  // ws kernel: left padding columns materialised in LDS (0 = unpadded rows + lane masks)
     int chunk;                 // consecutive pixel tiles one XCD takes before the next XCD's run starts
+    int ptab_off;              // byte offset in dynamic LDS of the epilogue's copy of the S_w prefix rows (0 = none)
     unsigned long long *dbg;   // diagnostic builds (-DQE_STAMP) only: per-wave phase cycle sums
     // raw operands, used by the flat 1x1 kernel (it builds its epilogue constants itself)
     const uint8_t *w_raw;      // packed OIHW weights as the caller passed them
@@ -128,7 +129,8 @@ struct TileGeom {
 template <int WM, int WN, int NIW>
 __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW], const int (&sxs)[NIW],
                                               const bool need_sx, const TileGeom g, const int ot,
-                                              const int wm, const int wn, const int col, const int h, const int KK)
+                                              const int wm, const int wn, const int col, const int h, const int KK,
+                                              const int *ptab = nullptr)   // LDS copy of this tile's rows of a.ws, or null
 {
     constexpr int MT = 32 * WM;
     const float zxp = a.x_zero[0] - zero_shift(a.x_bits, a.x_sign);
@@ -194,7 +196,7 @@ __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW
         for (int r = 0; r < 16; ++r) {
             const int oc = oc_base + (r & 3) + 8 * (r >> 2);
             zw[r] = a.ep[a.OCP + oc];
-            swt[r] = need_sw ? a.ws[(int64_t)oc * PS + PS - 1] : 0;
+            swt[r] = !need_sw ? 0 : (ptab ? ptab[(oc - ot * MT) * PS + PS - 1] : a.ws[(int64_t)oc * PS + PS - 1]);
         }
 #pragma unroll
         for (int t = 0; t < NIW; ++t) {
@@ -221,7 +223,7 @@ __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW
                 if (need_sw) {
                     int sw_sum = swt[r];
                     if (!interior) {
-                        const int *P = a.ws + (int64_t)oc * PS;
+                        const int *P = ptab ? ptab + (oc - ot * MT) * PS : a.ws + (int64_t)oc * PS;
                         sw_sum = P[i11] - P[i01] - P[i10] + P[i00];
                     }
                     v = fmaf(-zxp, (float)sw_sum, v);
@@ -232,6 +234,22 @@ __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW
             }
         }
     }
+}
+
+// Asymmetric activations (zx' != 0): the border-aware S_w lookups of the epilogue go to an LDS copy of this tile's MT
+// rows of the prefix table instead of global memory (a.ptab_off = byte offset of the copy in dynamic LDS, 0 = none).
+// Workgroup-uniform; contains a barrier.
+template <int MT>
+__device__ __forceinline__ const int *stage_ptab(const MfmaArgs &a, uint8_t *smem_base, int ot, int tid, int nthreads)
+{
+    const float zxp = a.x_zero[0] - zero_shift(a.x_bits, a.x_sign);
+    if (a.ptab_off == 0 || zxp == 0.0f) return nullptr;
+    const int PS = (a.KH + 1) * (a.KW + 1);
+    int *t = reinterpret_cast<int *>(smem_base + a.ptab_off);
+    const int *src = a.ws + (int64_t)ot * MT * PS;
+    for (int i = tid; i < MT * PS; i += nthreads) t[i] = src[i];
+    __syncthreads();
+    return t;
 }
 
 // tile decode shared by both kernels.  XCD-aware block map: blocks b and b+8 share an XCD (and its
@@ -508,7 +526,10 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs
 #ifdef QE_STAMP
     QE_ST(6);       // (prologue of the epilogue)
 #endif
-    mfma_epilogue<WM, WN, NIW>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK);
+    {
+        const int *ptab = stage_ptab<32 * WM>(a, smem, ot, tid, MF_THREADS);
+        mfma_epilogue<WM, WN, NIW>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab);
+    }
 #ifdef QE_STAMP
     QE_ST(7);       // epilogue stores issued
     if (a.dbg != nullptr && lane == 0) {
@@ -779,8 +800,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_sm2_kernel(const Mfma
         }
     }
     QE_ST(6);
-    mfma_epilogue<2 * WMS, WN, NTC>(a, acc0, sxs, need_sx, g, ot, 2 * wms, wn, col, h, KK);
-    mfma_epilogue<2 * WMS, WN, NTC>(a, acc1, sxs, need_sx, g, ot, 2 * wms + 1, wn, col, h, KK);
+    const int *ptab = stage_ptab<MT>(a, smem, ot, tid, MF_THREADS);
+    mfma_epilogue<2 * WMS, WN, NTC>(a, acc0, sxs, need_sx, g, ot, 2 * wms, wn, col, h, KK, ptab);
+    mfma_epilogue<2 * WMS, WN, NTC>(a, acc1, sxs, need_sx, g, ot, 2 * wms + 1, wn, col, h, KK, ptab);
 #ifdef QE_STAMP
     QE_ST(7);
     if (a.dbg != nullptr && lane == 0) {
@@ -1235,7 +1257,10 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_smallic_kernel(const 
             }
         }
     }
-    mfma_epilogue<WM, WN, NIW>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK);
+    {
+        const int *ptab = stage_ptab<32 * WM>(a, reinterpret_cast<uint8_t *>(smem), ot, tid, MF_THREADS);
+        mfma_epilogue<WM, WN, NIW>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab);
+    }
 }
 
 
