@@ -676,6 +676,22 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
         const size_t off = align_up(p.lds, 16);
         if (off + tab <= (size_t)(p.sm2 ? MF_MAX_LDS_SM2 : MF_MAX_LDS)) { a.ptab_off = (int)off; lds_e = off + tab; }
     }
+    // border classes: rows r < n_top have their top taps clipped, the last n_bot rows their bottom taps (columns alike).
+    // The class table needs the bands disjoint and (classes) <= (prefix entries per channel) to fit the same LDS slot.
+    {
+        auto clipped_lo = [](int pad, int stride, int O) { return std::min(O, (pad + stride - 1) / stride); };
+        auto clipped_hi = [](int I, int pad, int K, int stride, int O) {
+            const int full_last = (I + pad - K) >= 0 ? (I + pad - K) / stride : -1;   // last output index with all taps below the edge
+            return std::max(0, std::min(O, O - 1 - full_last));
+        };
+        a.n_top = clipped_lo(sh->padding, sh->stride, p.OH);
+        a.n_bot = clipped_hi(sh->H, sh->padding, sh->KH, sh->stride, p.OH);
+        a.n_lft = clipped_lo(sh->padding, sh->stride, p.OW);
+        a.n_rgt = clipped_hi(sh->W, sh->padding, sh->KW, sh->stride, p.OW);
+        const int ncls = (1 + a.n_top + a.n_bot) * (1 + a.n_lft + a.n_rgt);
+        a.ctab = (a.ptab_off != 0 && a.n_top + a.n_bot < p.OH && a.n_lft + a.n_rgt < p.OW &&
+                  ncls <= (sh->KH + 1) * (sh->KW + 1) && !(getenv("QE_CTAB") && atoi(getenv("QE_CTAB")) == 0)) ? 1 : 0;
+    }
     if (p.flatg) {
         launch_mfma_flatg(a, p.NS, p.wraw, (unsigned)blocks, p.lds, s);
         QE_LAUNCH_CHECK();

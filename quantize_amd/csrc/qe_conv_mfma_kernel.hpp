@@ -34,7 +34,9 @@ struct MfmaArgs {
     int GI;                    // whole images per pixel tile (> 1 only for small feature maps, TH == OH)
     int PADW;                  // ws kernel: left padding columns materialised in LDS (0 = unpadded rows + lane masks)
     int chunk;                 // consecutive pixel tiles one XCD takes before the next XCD's run starts
-    int ptab_off;              // byte offset in dynamic LDS of the epilogue's copy of the S_w prefix rows (0 = none)
+    int ptab_off;              // byte offset in dynamic LDS of the epilogue's S_w table (0 = none)
+    int ctab;                  // 1: that table is the per-(border class, channel) correction (stage_ctab), 0: prefix rows
+    int n_top, n_bot, n_lft, n_rgt;   // output rows / columns whose taps are clipped at each image edge
     unsigned long long *dbg;   // diagnostic builds (-DQE_STAMP) only: per-wave phase cycle sums
     // raw operands, used by the flat 1x1 kernel (it builds its epilogue constants itself)
     const uint8_t *w_raw;      // packed OIHW weights as the caller passed them
@@ -130,7 +132,8 @@ template <int WM, int WN, int NIW>
 __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW], const int (&sxs)[NIW],
                                               const bool need_sx, const TileGeom g, const int ot,
                                               const int wm, const int wn, const int col, const int h, const int KK,
-                                              const int *ptab = nullptr)   // LDS copy of this tile's rows of a.ws, or null
+                                              const int *ptab = nullptr,   // LDS copy of this tile's rows of a.ws, or null
+                                              const float *ctab = nullptr) // LDS [border class][MT] correction table, or null
 {
     constexpr int MT = 32 * WM;
     const float zxp = a.x_zero[0] - zero_shift(a.x_bits, a.x_sign);
@@ -189,6 +192,35 @@ __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW
         // pixels use the per-channel total (one load per channel, hoisted out of the tile loop), border pixels four
         // table entries.  No per-tap loop, no per-element table walk (the first version cost 3-6x on 3x3 layers and
         // 17x on the 7x7 stem).
+        if (ctab != nullptr) {
+            // One table lookup per element: T[class][oc] = -zx' S_w(oc, class) + N_inb(class) IC zx' zw'[oc], the class of
+            // a pixel being (which clipped row band, which clipped column band) -- no branch between interior and border.
+            float zwc[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zwc[r] = need_sx ? a.ep[a.OCP + oc_base + (r & 3) + 8 * (r >> 2)] : 0.0f;
+            const int ncc = 1 + a.n_lft + a.n_rgt;
+            const float *crow = ctab + (oc_base - ot * MT);
+#pragma unroll
+            for (int t = 0; t < NIW; ++t) {
+                const int q = (wn + t * WN) * 32 + col;
+                const int gi = valid[t] ? q / g.OHWt : 0;
+                const int rq = valid[t] ? q - gi * g.OHWt : 0;
+                const int rr = rq / a.OW, c = rq - rr * a.OW;
+                const int ra = g.oh0 + rr;
+                const int rid = ra < a.n_top ? 1 + ra : (ra >= a.OH - a.n_bot ? 1 + a.n_top + (a.OH - 1 - ra) : 0);
+                const int cid = c < a.n_lft ? 1 + c : (c >= a.OW - a.n_rgt ? 1 + a.n_lft + (a.OW - 1 - c) : 0);
+                const float *ct = crow + (rid * ncc + cid) * MT;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    float v = (float)acc[t][r] + ct[dr];
+                    if (need_sx) v = fmaf(-zwc[r], (float)sxs[t], v);
+                    const float res = fmaf(al[r], v, bi[r]);
+                    if (valid[t] && oc_base + dr < a.OC) (out_w + (int64_t)dr * OHW)[voff[t]] = res;
+                }
+            }
+            return;
+        }
         float zw[16];
         int swt[16];
         const int PW1 = a.KW + 1, PS = (a.KH + 1) * PW1;
@@ -248,6 +280,35 @@ __device__ __forceinline__ const int *stage_ptab(const MfmaArgs &a, uint8_t *sme
     int *t = reinterpret_cast<int *>(smem_base + a.ptab_off);
     const int *src = a.ws + (int64_t)ot * MT * PS;
     for (int i = tid; i < MT * PS; i += nthreads) t[i] = src[i];
+    __syncthreads();
+    return t;
+}
+
+// The class form of the same correction (a.ctab): band 0 = no clipping, 1..n_top = output rows 0..n_top-1 (top taps
+// clipped), then the last n_bot rows from the bottom up; columns alike.  Built per workgroup from the global prefix
+// table: (1 + n_top + n_bot)(1 + n_lft + n_rgt) x MT floats in the LDS slot at a.ptab_off.  Contains a barrier.
+template <int MT>
+__device__ __forceinline__ const float *stage_ctab(const MfmaArgs &a, uint8_t *smem_base, int ot, int tid, int nthreads)
+{
+    const float zxp = a.x_zero[0] - zero_shift(a.x_bits, a.x_sign);
+    if (a.ptab_off == 0 || a.ctab == 0 || zxp == 0.0f) return nullptr;
+    const int PW1 = a.KW + 1, PS = (a.KH + 1) * PW1;
+    const int nrc = 1 + a.n_top + a.n_bot, ncc = 1 + a.n_lft + a.n_rgt;
+    float *t = reinterpret_cast<float *>(smem_base + a.ptab_off);
+    for (int i = tid; i < nrc * ncc * MT; i += nthreads) {
+        const int cls = i / MT, ocl = i - cls * MT;
+        const int rid = cls / ncc, cid = cls - rid * ncc;
+        const int rrep = rid == 0 ? a.n_top : (rid <= a.n_top ? rid - 1 : a.OH - 1 - (rid - 1 - a.n_top));
+        const int crep = cid == 0 ? a.n_lft : (cid <= a.n_lft ? cid - 1 : a.OW - 1 - (cid - 1 - a.n_lft));
+        const int ihb = rrep * a.stride - a.pad, iwb = crep * a.stride - a.pad;
+        const int kh_lo = max(0, -ihb), kh_hi = max(kh_lo, min(a.KH, a.H - ihb));
+        const int kw_lo = max(0, -iwb), kw_hi = max(kw_lo, min(a.KW, a.W - iwb));
+        const int oc = ot * MT + ocl;
+        const int *P = a.ws + (int64_t)oc * PS;
+        const int sw_sum = P[kh_hi * PW1 + kw_hi] - P[kh_lo * PW1 + kw_hi] - P[kh_hi * PW1 + kw_lo] + P[kh_lo * PW1 + kw_lo];
+        const float fn = (float)((kh_hi - kh_lo) * (kw_hi - kw_lo) * a.IC);
+        t[i] = fmaf(fn * zxp, a.ep[a.OCP + oc], -zxp * (float)sw_sum);
+    }
     __syncthreads();
     return t;
 }
@@ -527,8 +588,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs
     QE_ST(6);       // (prologue of the epilogue)
 #endif
     {
-        const int *ptab = stage_ptab<32 * WM>(a, smem, ot, tid, MF_THREADS);
-        mfma_epilogue<WM, WN, NIW>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab);
+        const float *ctab = stage_ctab<32 * WM>(a, smem, ot, tid, MF_THREADS);
+        const int *ptab = ctab ? nullptr : stage_ptab<32 * WM>(a, smem, ot, tid, MF_THREADS);
+        mfma_epilogue<WM, WN, NIW>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab, ctab);
     }
 #ifdef QE_STAMP
     QE_ST(7);       // epilogue stores issued
@@ -800,9 +862,10 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_sm2_kernel(const Mfma
         }
     }
     QE_ST(6);
-    const int *ptab = stage_ptab<MT>(a, smem, ot, tid, MF_THREADS);
-    mfma_epilogue<2 * WMS, WN, NTC>(a, acc0, sxs, need_sx, g, ot, 2 * wms, wn, col, h, KK, ptab);
-    mfma_epilogue<2 * WMS, WN, NTC>(a, acc1, sxs, need_sx, g, ot, 2 * wms + 1, wn, col, h, KK, ptab);
+    const float *ctab = stage_ctab<MT>(a, smem, ot, tid, MF_THREADS);
+    const int *ptab = ctab ? nullptr : stage_ptab<MT>(a, smem, ot, tid, MF_THREADS);
+    mfma_epilogue<2 * WMS, WN, NTC>(a, acc0, sxs, need_sx, g, ot, 2 * wms, wn, col, h, KK, ptab, ctab);
+    mfma_epilogue<2 * WMS, WN, NTC>(a, acc1, sxs, need_sx, g, ot, 2 * wms + 1, wn, col, h, KK, ptab, ctab);
 #ifdef QE_STAMP
     QE_ST(7);
     if (a.dbg != nullptr && lane == 0) {
@@ -1258,8 +1321,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_smallic_kernel(const 
         }
     }
     {
-        const int *ptab = stage_ptab<32 * WM>(a, reinterpret_cast<uint8_t *>(smem), ot, tid, MF_THREADS);
-        mfma_epilogue<WM, WN, NIW>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab);
+        const float *ctab = stage_ctab<32 * WM>(a, reinterpret_cast<uint8_t *>(smem), ot, tid, MF_THREADS);
+        const int *ptab = ctab ? nullptr : stage_ptab<32 * WM>(a, reinterpret_cast<uint8_t *>(smem), ot, tid, MF_THREADS);
+        mfma_epilogue<WM, WN, NIW>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab, ctab);
     }
 }
 
