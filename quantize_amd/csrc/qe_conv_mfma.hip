@@ -671,7 +671,7 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     // LDS room for the epilogue's copy of the tile's S_w prefix rows (asymmetric activations; stage_ptab)
     size_t lds_e = p.lds;
     a.ptab_off = 0;
-    if (!p.flat && !p.flatg && !p.ws) {
+    if (!p.flat && !p.flatg) {
         const size_t tab = (size_t)p.MT * (sh->KH + 1) * (sh->KW + 1) * sizeof(int);
         const size_t off = align_up(p.lds, 16);
         if (off + tab <= (size_t)(p.sm2 ? MF_MAX_LDS_SM2 : MF_MAX_LDS)) { a.ptab_off = (int)off; lds_e = off + tab; }
@@ -713,7 +713,8 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
         {
             const int units = p.GI * p.IHT * ((sh->W + 3) / 4);
             const int split = units <= 64 ? 4 : (units <= 128 ? 2 : 1);   // idle producer threads take channel slices
-            launch_mfma_ws(a, p.niw, split, (unsigned)blocks, p.lds, s);
+            // (without the class table the ws epilogue reads the prefix rows from global memory: no LDS slot needed)
+            launch_mfma_ws(a, p.niw, split, (unsigned)blocks, a.ctab ? lds_e : p.lds, s);
         }
         QE_LAUNCH_CHECK();
         return QE_OK;

@@ -210,13 +210,24 @@ __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW
                 const int rid = ra < a.n_top ? 1 + ra : (ra >= a.OH - a.n_bot ? 1 + a.n_top + (a.OH - 1 - ra) : 0);
                 const int cid = c < a.n_lft ? 1 + c : (c >= a.OW - a.n_rgt ? 1 + a.n_lft + (a.OW - 1 - c) : 0);
                 const float *ct = crow + (rid * ncc + cid) * MT;
+                const int q0 = (wn + t * WN) * 32;
+                if (full_oc && q0 + 32 <= g.NT) {      // wave-uniform: plain stores, no per-element exec masks
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dr = (r & 3) + 8 * (r >> 2);
-                    float v = (float)acc[t][r] + ct[dr];
-                    if (need_sx) v = fmaf(-zwc[r], (float)sxs[t], v);
-                    const float res = fmaf(al[r], v, bi[r]);
-                    if (valid[t] && oc_base + dr < a.OC) (out_w + (int64_t)dr * OHW)[voff[t]] = res;
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = (r & 3) + 8 * (r >> 2);
+                        float v = (float)acc[t][r] + ct[dr];
+                        if (need_sx) v = fmaf(-zwc[r], (float)sxs[t], v);
+                        (out_w + (int64_t)dr * OHW)[voff[t]] = fmaf(al[r], v, bi[r]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = (r & 3) + 8 * (r >> 2);
+                        float v = (float)acc[t][r] + ct[dr];
+                        if (need_sx) v = fmaf(-zwc[r], (float)sxs[t], v);
+                        const float res = fmaf(al[r], v, bi[r]);
+                        if (valid[t] && oc_base + dr < a.OC) (out_w + (int64_t)dr * OHW)[voff[t]] = res;
+                    }
                 }
             }
             return;
@@ -927,6 +938,9 @@ __global__ __launch_bounds__(2 * MF_THREADS, 2) void conv_mfma_ws_kernel(const M
     for (int i = tid; i < 2 * BUF; i += 2 * MF_THREADS) Xs[i] = make_uint4(0, 0, 0, 0);
     for (int i = tid; i < GSZ; i += 2 * MF_THREADS) sxp[i] = 0;
 
+    // asymmetric activations: the epilogue's border-class table is built now, while all eight waves are here
+    const float *ctab = stage_ctab<MT>(a, smem, ot, tid, 2 * MF_THREADS);
+
     int zw_local = 0;
     if (tid < MT) zw_local = (a.ep[a.OCP + ot * MT + tid] != 0.0f) ? 1 : 0;
     const bool need_sx = __syncthreads_or(zw_local) != 0;  // also orders the LDS zero fill
@@ -1168,7 +1182,7 @@ __global__ __launch_bounds__(2 * MF_THREADS, 2) void conv_mfma_ws_kernel(const M
                 if ((km[t] >> (tap % KW_T)) & 1u) sxs[t] += sxp[pbase + (tap / KW_T) * a.IWP + (tap % KW_T)];
         }
     }
-    mfma_epilogue<WM, WN, NIW>(a, acc, sxs, need_sx, g, ot, cw, 0, col, h, KKT);
+    mfma_epilogue<WM, WN, NIW>(a, acc, sxs, need_sx, g, ot, cw, 0, col, h, KKT, nullptr, ctab);
 #ifdef QE_STAMP
     QE_ST(7);
     if (a.dbg != nullptr && lane == 0) {
