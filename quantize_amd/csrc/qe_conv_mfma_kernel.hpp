@@ -1625,12 +1625,20 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
         // same wave wrote and reads: only the LDS counter has to drain
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
         const bool px_ok = q0 + 4 * rq < NT;
+        if (q0 + 32 <= NT && ot * MT + wm * 32 + 32 <= a.OC) {   // wave-uniform: whole 32 x 32 tile inside, plain stores
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 8 * i + rrow;
-            const float4 o4 = *reinterpret_cast<const float4 *>(patch + row * 36 + 4 * rq);
-            if (px_ok && ot * MT + wm * 32 + row < a.OC)
+            for (int i = 0; i < 4; ++i) {
+                const float4 o4 = *reinterpret_cast<const float4 *>(patch + (8 * i + rrow) * 36 + 4 * rq);
                 *reinterpret_cast<float4 *>(out_w + (int64_t)(8 * i) * P + q0 + voff) = o4;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 8 * i + rrow;
+                const float4 o4 = *reinterpret_cast<const float4 *>(patch + row * 36 + 4 * rq);
+                if (px_ok && ot * MT + wm * 32 + row < a.OC)
+                    *reinterpret_cast<float4 *>(out_w + (int64_t)(8 * i) * P + q0 + voff) = o4;
+            }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);   // reads done before the next tile overwrites the patch
     }

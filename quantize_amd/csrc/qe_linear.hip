@@ -319,12 +319,22 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a)
                 for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + col] = v[r];
                 __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): same wave wrote and reads
                 const int c4 = n0 + wn * 32 * NJ + j * 32 + 4 * rq;
+                const int64_t row0 = m0 + wm * 64 + i * 32;
+                if (row0 + 32 <= a.B && n0 + wn * 32 * NJ + j * 32 + 32 <= a.O) {   // wave-uniform: plain stores
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int rt = 8 * k + rrow;
-                    const float4 o4 = *reinterpret_cast<const float4 *>(patch + rt * 36 + 4 * rq);
-                    const int64_t row = m0 + wm * 64 + i * 32 + rt;
-                    if (row < a.B && c4 < a.O) *reinterpret_cast<float4 *>(a.out + row * a.O + c4) = o4;
+                    for (int k = 0; k < 4; ++k) {
+                        const int rt = 8 * k + rrow;
+                        const float4 o4 = *reinterpret_cast<const float4 *>(patch + rt * 36 + 4 * rq);
+                        *reinterpret_cast<float4 *>(a.out + (row0 + rt) * a.O + c4) = o4;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int rt = 8 * k + rrow;
+                        const float4 o4 = *reinterpret_cast<const float4 *>(patch + rt * 36 + 4 * rq);
+                        const int64_t row = row0 + rt;
+                        if (row < a.B && c4 < a.O) *reinterpret_cast<float4 *>(a.out + row * a.O + c4) = o4;
+                    }
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f);   // reads done before the next tile overwrites the patch
             } else {
