@@ -36,8 +36,8 @@ INT8_MFMA_PEAK_TOPS = 5000.0  # dense int8 = 2x bf16 (~2.5 PF)
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--w-bits", type=int, default=8)
     ap.add_argument("--a-bits", type=int, default=8)
@@ -48,6 +48,8 @@ def parse_args():
                          "the stack (repeating one layer keeps its input in the 256 MB Infinity Cache otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=16, help="images of the CPU-baseline sample (about 15 s on 16 cores)")
+    ap.add_argument("--cpu-fallback-images", type=int, default=32,
+                    help="images of the reference-fallback sample (torch-CPU F.conv2d on dequantised tensors)")
     ap.add_argument("--layers", type=str, default="", help="comma list of layer indices (debug)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the 53 layer calls as one captured hipGraph instead of launching them one by one "
@@ -90,13 +92,8 @@ class Layer:
             raise RuntimeError("qe_quantconv2d failed on layer %s: %d" % (self.spec.name, rc))
 
 
-def cpu_baseline(layers, args, torch):
-    """The oracle (CPU restatement of quantconv2d.cu:78-141, fp32 mul+add chain) on a bounded sample:
-    the first `cpu_images` images of every layer's batch, OpenMP over outputs on all host cores."""
-    import numpy as np
-    import oracle
-    n_img = args.cpu_images
-    # the cores this process may really use (cgroup quota / affinity), not the host's core count
+def usable_cores():
+    """The cores this process may really use (cgroup quota / affinity), not the host's core count."""
     avail = len(os.sched_getaffinity(0))
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -104,6 +101,51 @@ def cpu_baseline(layers, args, torch):
             avail = max(1, min(avail, int(int(quota) / int(period))))
     except Exception:
         pass
+    return avail
+
+
+def cpu_fallback_baseline(layers, args, torch):
+    """north_star's "reference's CPU fallback": what the reference's packed QuantConv2d.forward really executes
+    today (modelzoo/modules/quantconv2d.py:207-210, the native call is commented out): dequantise both operands and
+    call F.conv2d -- here on the host cores through torch-CPU (oneDNN), all usable cores, on the first
+    `cpu_fallback_images` images of every layer's batch.  The dequantisation is inside the timed region, as it is
+    inside the reference's forward.  No reference code runs: the integer codes come from the engine's own tunpack."""
+    import torch.nn.functional as F
+    from quantize_amd import capi
+    n_img = args.cpu_fallback_images
+    cores = usable_cores()
+    old = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    work = []
+    for L in layers:
+        sp = L.spec
+        n_x = n_img * sp.IC * sp.H * sp.H
+        qx = capi.tunpack(L.xp[: (n_x * args.a_bits + 7) // 8], n_x, args.a_bits, L.x_sign).reshape(n_img, sp.IC, sp.H, sp.H).cpu()
+        qw = capi.tunpack(L.wp, sp.OC * sp.IC * sp.K * sp.K, args.w_bits, True).reshape(sp.OC, sp.IC, sp.K, sp.K).cpu()
+        work.append((qx, L.sx.cpu(), L.zx.cpu(), qw, L.sw.cpu().reshape(-1, 1, 1, 1), L.zw.cpu().reshape(-1, 1, 1, 1),
+                     None if L.bias is None else L.bias.cpu(), sp.stride, sp.pad))
+    def run():
+        for qx, sx, zx, qw, sw, zw, b, st, pd in work:
+            F.conv2d((qx.float() - zx) * sx, (qw.float() - zw) * sw, b, st, pd)
+    with torch.no_grad():
+        run()                      # warm-up: oneDNN primitive creation
+        t0 = time.perf_counter()
+        run()
+        dt = time.perf_counter() - t0
+    torch.set_num_threads(old)
+    return {"value": n_img / dt, "unit": "images/s", "cores": cores, "threads": cores, "kind": "reference-fallback",
+            "sample": "%d images through all %d conv layers: torch-CPU F.conv2d((q - z) * s, (q - z) * s, bias) as in "
+                      "the reference's packed forward (quantconv2d.py:207-210), dequantisation timed, %.1f s"
+                      % (n_img, len(layers), dt)}
+
+
+def cpu_baseline(layers, args, torch):
+    """The oracle (CPU restatement of quantconv2d.cu:78-141, fp32 mul+add chain) on a bounded sample:
+    the first `cpu_images` images of every layer's batch, OpenMP over outputs on all host cores."""
+    import numpy as np
+    import oracle
+    n_img = args.cpu_images
+    avail = usable_cores()
     oracle.set_num_threads(avail)
     threads = oracle.num_threads()
     work = []
@@ -120,7 +162,7 @@ def cpu_baseline(layers, args, torch):
     for w in work:
         oracle.quantconv2d(*w, mode="fp32")
     dt = time.perf_counter() - t0
-    return {"value": n_img / dt, "unit": "images/s", "cores": threads, "kind": "port",
+    return {"value": n_img / dt, "unit": "images/s", "cores": threads, "threads": threads, "kind": "port",
             "sample": "%d images through all %d conv layers (oracle/qe_oracle.c, OpenMP over outputs), %.1f s"
                       % (n_img, len(layers), dt)}
 
@@ -172,7 +214,7 @@ def main():
         else:                                       # --layers debug subsets ending on a large map
             feats = last.out.mean(dim=(2, 3))
         logits = feats @ fc_w.t()
-        logits = qdist.gather_logits(logits) if world > 1 else logits
+        logits = qdist.gather_logits(logits, equal_shards=True) if world > 1 else logits
         return logits.argmax(dim=1)
 
     # --graph: capture the ~73 kernel launches of a step (53 convs + 20 weight preps) once into a hipGraph and
@@ -270,11 +312,18 @@ def main():
         print("sum of isolated layer times: %.3f ms" % tot, file=sys.stderr)
 
     if rank == 0:
-        traffic = None
+        # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/profile_round.sh); the file records
+        # the fingerprint of the kernel sources it was measured at and the number is reported only while the sources
+        # are still those -- otherwise null, never a stale figure.
+        traffic, traffic_tag = None, None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
-        if os.path.exists(tpath) and not args.layers and N == 256 and args.w_bits == 8 and args.a_bits == 8:
+        if os.path.exists(tpath) and not args.layers and N == 256 and args.w_bits == 8 and args.a_bits == 8 \
+                and not args.asymmetric:
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                from quantize_amd.build import source_sha16
+                tj = json.load(open(tpath))
+                if tj.get("source_sha16") == source_sha16():
+                    traffic, traffic_tag = tj.get("hbm_bytes_per_launch"), tj.get("tag")
             except Exception:
                 traffic = None
         result = {
@@ -302,6 +351,7 @@ def main():
                          "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": traffic,
+                         "traffic_measured_at": traffic_tag,
                          "bytes_per_launch": total_bytes / n_launch,
                          "avg_launch_ms": conv_ms / n_launch,
                          "conv_stack_ms": conv_ms,
@@ -309,7 +359,10 @@ def main():
                          "mfma_frac": total_ops / (conv_ms * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS},
         }
         if world == 1 and not args.no_cpu_baseline:
+            # two legs on the box's host cores: the CPU port of the reference KERNEL (oracle) and the reference's own
+            # packed-forward FALLBACK (F.conv2d on dequantised tensors), which is what north_star names
             result["cpu_baseline"] = cpu_baseline(layers, args, torch)
+            result["cpu_baseline_fallback"] = cpu_fallback_baseline(layers, args, torch)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -288,16 +288,46 @@ def gen_g4():
         ("w8_layer_a6", 12, 10, 3, 1, 1,
          dict(n_bits=8, symmetric=True, signed=True, granularity="layer", range={"name": "minmax"}),
          dict(n_bits=6, symmetric=True, signed=True, granularity="layer", range={"name": "minmax"})),
+        # round 2: asymmetric per-channel weights on a padded stride-2 3x3 (border-aware zero terms with
+        # non-integer zero points), BatchNorm folded into the weight scale with NEGATIVE gammas (negative w_scale,
+        # quantconv2d.py:127-133), BatchNorm folded into the weights of a bias-free conv (:115-126), 4-bit
+        # asymmetric activations, W4A4 asymmetric
+        ("w8a8_asym_pc_s2", 32, 24, 3, 2, 1,
+         dict(n_bits=8, symmetric=False, signed=False, granularity="channel", range={"name": "minmax"}),
+         dict(n_bits=8, symmetric=False, signed=False, granularity="layer", range={"name": "minmax"}), 14, None),
+        ("w8a8_bn_into_scale_neg", 16, 12, 3, 1, 1,
+         dict(n_bits=8, symmetric=True, signed=True, granularity="channel", range={"name": "minmax"}),
+         dict(n_bits=8, symmetric=True, signed=True, granularity="layer", range={"name": "minmax"}), 14, "into_scale"),
+        ("w8a8_bn_into_weight_nobias", 16, 12, 1, 1, 0,
+         dict(n_bits=8, symmetric=False, signed=False, granularity="channel", range={"name": "minmax"}),
+         dict(n_bits=8, symmetric=True, signed=True, granularity="layer", range={"name": "minmax"}), 7, "into_weight"),
+        ("w8a4_asym", 24, 16, 3, 1, 1,
+         dict(n_bits=8, symmetric=True, signed=True, granularity="channel", range={"name": "minmax"}),
+         dict(n_bits=4, symmetric=False, signed=False, granularity="layer", range={"name": "minmax"}), 8, None),
+        ("w4a4_asym_s2", 16, 20, 3, 2, 1,
+         dict(n_bits=4, symmetric=False, signed=False, granularity="channel", range={"name": "minmax"}),
+         dict(n_bits=4, symmetric=False, signed=False, granularity="layer", range={"name": "minmax"}), 9, None),
     ]
-    for (name, cin, cout, k, stride, pad, w_set, a_set) in cfgs:
-        conv = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=True)
-        x = torch.randn(4, cin, 12, 12)
+    for cfg in cfgs:
+        (name, cin, cout, k, stride, pad, w_set, a_set) = cfg[:8]
+        Hin = cfg[8] if len(cfg) > 8 else 12
+        bn_mode = cfg[9] if len(cfg) > 9 else None
+        conv = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=(bn_mode != "into_weight"))
+        x = torch.randn(4, cin, Hin, Hin)
         x = torch.relu(x) if not a_set["symmetric"] else x
+        if len(cfg) > 8 and not a_set["symmetric"]:
+            x = x + 0.37               # min > 0: a non-zero, non-integer activation zero point (minmax.py:143)
+        bn = {}
+        if bn_mode is not None:
+            gamma = torch.randn(cout)           # about half of the BatchNorm weights negative
+            bn = {"weight": gamma, "bias": torch.randn(cout) * 0.1, "running_mean": torch.randn(cout) * 0.1,
+                  "running_var": torch.rand(cout) + 0.5, "eps": 1e-5, "into_scale": bn_mode == "into_scale"}
 
         def make():
             return mm.QuantConv2d(cin, cout, k, stride=stride, padding=pad, w_setting=w_set, a_setting=a_set,
+                                  bn_folding={kk: (vv.clone() if torch.is_tensor(vv) else vv) for kk, vv in bn.items()},
                                   _parameters={"weight": conv.weight.detach().clone(),
-                                               "bias": conv.bias.detach().clone()})
+                                               "bias": None if conv.bias is None else conv.bias.detach().clone()})
 
         m = make()
         with torch.no_grad():

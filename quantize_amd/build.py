@@ -32,6 +32,19 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_sha16():
+    """Fingerprint of the kernel sources (csrc/* + include/quant_engine.h).  profiles/traffic.json records the
+    fingerprint its PMC passes were measured at; bench.py reports `roofline.traffic` only while it still matches
+    (the GPU box has no .git, so a commit id cannot be checked there)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h", ".cpp")))
+    for f in files + [os.path.join(INCLUDE, "quant_engine.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def lib_path():
     return os.path.join(EXT_DIR, "libqe_hip.so")
 

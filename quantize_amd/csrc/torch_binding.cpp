@@ -8,10 +8,13 @@
 // allocator and picks up torch's current device and stream (the reference launches
 // on the legacy default stream with no device guard).
 //
+// tpack/tunpack dispatch on the tensor's device exactly like the reference (tpack.cu:241-251, :458-468):
+// device tensors go to the HIP kernels, CPU-resident tensors (a model packed or reloaded before it was
+// moved to the GPU, cfg.device='cpu') to the host loops below.  That is the reference's own contract for
+// host data, not a fallback: GPU tensors never take it, and a missing HIP build still fails at import.
+// The conv / linear operators stay device-only, as in the reference (CHECK_CUDA, quantconv2d.cu:13,178).
+//
 // Deliberate differences from the reference, all stricter:
-//   * device tensors only -- CPU tensors raise "x must be a CUDA tensor" instead of
-//     taking a host loop (the reference's tpack_cpu/tunpack_cpu, tpack.cu:140,371);
-//     this build has no CPU compute path at all;
 //   * extra TORCH_CHECKs where the reference would read out of bounds (packed buffer
 //     shorter than the description says, scale arrays that are neither 1 nor C long);
 //   * 64-bit indexing (the reference overflows 32-bit beyond 2^31 bits).
@@ -88,15 +91,75 @@ Des read_des(const torch::Tensor &des)
 }
 
 // ------------------------------------------------------------------------------------------
+// Host loops for CPU-resident tensors (reference: tpack_cpu tpack.cu:140-190, tunpack_cpu :371-419).
+// Same bit stream as the kernels: element i occupies bits [i*b, (i+1)*b) LSB first, stored value
+// u = (uchar)(char)x + offset.  The reference walks the tensor with one .item() per element and a byte
+// read-modify-write per half; here the elements go through a 64-bit shift register that is flushed a byte
+// at a time (no RMW, output need not be pre-zeroed).  The range check (tpack.cu:211-215) runs in the same pass.
+// ------------------------------------------------------------------------------------------
+std::vector<torch::Tensor> tpack_host(const torch::Tensor &x, int n_bits, bool sign)
+{
+    (void)to_qe_dtype(x, "tpack_cpu");                     // same dtype set as the device path
+    const int64_t n = x.numel();
+    const auto xf = x.reshape({-1}).to(torch::kFloat);      // x[i].item<float>() of the reference, vectorised
+    const float *src = xf.data_ptr<float>();
+    const float lo = sign ? -(float)(1 << (n_bits - 1)) : 0.0f;
+    const float hi = sign ? (float)((1 << (n_bits - 1)) - 1) : (float)((1 << n_bits) - 1);
+    bool in_range = true;
+    for (int64_t i = 0; i < n; ++i) in_range = in_range && (src[i] >= lo && src[i] <= hi);   // NaN fails, as in CHECK_RANGE
+    TORCH_CHECK(in_range, "The input tensor is out of range.");
+
+    auto x_out = torch::empty({qe_packed_nbytes(n, n_bits)}, torch::dtype(torch::kByte));
+    uint8_t *dst = x_out.data_ptr<uint8_t>();
+    const unsigned offset = sign ? (1u << (n_bits - 1)) : 0u;
+    const unsigned mask = (1u << n_bits) - 1u;
+    uint64_t reg = 0;
+    int fill = 0;
+    int64_t o = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const unsigned e = ((unsigned)(unsigned char)(signed char)src[i] + offset) & mask;
+        reg |= (uint64_t)e << fill;
+        fill += n_bits;
+        while (fill >= 8) { dst[o++] = (uint8_t)reg; reg >>= 8; fill -= 8; }
+    }
+    if (fill > 0) dst[o++] = (uint8_t)reg;
+
+    std::vector<int32_t> d;
+    d.push_back(n_bits);
+    d.push_back(sign ? 1 : 0);
+    for (auto s : x.sizes()) d.push_back((int32_t)s);
+    return {x_out, torch::tensor(d, torch::dtype(torch::kInt))};
+}
+
+torch::Tensor tunpack_host(const torch::Tensor &x, const Des &d)
+{
+    auto x_out = torch::empty({d.numel}, torch::dtype(d.sign ? torch::kChar : torch::kByte));
+    const uint8_t *src = x.data_ptr<uint8_t>();
+    uint8_t *dst = static_cast<uint8_t *>(x_out.data_ptr());
+    const unsigned offset = d.sign ? (1u << (d.n_bits - 1)) : 0u;
+    const unsigned mask = (1u << d.n_bits) - 1u;
+    uint64_t reg = 0;
+    int fill = 0;
+    int64_t in = 0;
+    for (int64_t i = 0; i < d.numel; ++i) {
+        while (fill < d.n_bits) { reg |= (uint64_t)src[in++] << fill; fill += 8; }
+        dst[i] = (uint8_t)(((unsigned)reg & mask) - offset);   // `element -= offset` in unsigned char, then (signed char)
+        reg >>= d.n_bits;
+        fill -= d.n_bits;
+    }
+    return x_out.reshape(d.shape);
+}
+
+// ------------------------------------------------------------------------------------------
 // tpack  (reference: engine/kernels/tpack/tpack.cu:203-255, tpack.h:17-20)
 // ------------------------------------------------------------------------------------------
 std::vector<torch::Tensor> tpack(torch::Tensor x, int n_bits, bool sign)
 {
     CHECK_NBITS(n_bits);
     CHECK_CONTIGUOUS(x);
-    CHECK_CUDA(x);
     TORCH_CHECK(x.numel() > 0,
                 "min(): Expected reduction dim to be specified for input.numel() == 0. Specify the reduction dim with the 'dim' argument.");
+    if (!x.device().is_cuda()) return tpack_host(x, n_bits, sign);   // tpack.cu:241-251
     const int dtype = to_qe_dtype(x, "tpack_cuda");
 
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
@@ -131,10 +194,10 @@ torch::Tensor tunpack(torch::Tensor x, torch::Tensor des)
     CHECK_NBITS(n_bits);
     CHECK_CONTIGUOUS(x);
     TORCH_CHECK(x.dtype() == torch::kByte, "The input tensor must be torch.uint8.");
-    CHECK_CUDA(x);
     TORCH_CHECK(d.numel >= 0, "The description holds a negative shape.");
     TORCH_CHECK(x.numel() >= qe_packed_nbytes(d.numel, n_bits),
                 "The packed tensor is shorter than its description requires.");
+    if (!x.device().is_cuda()) return tunpack_host(x, d);            // tpack.cu:458-468
 
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     auto x_out = torch::empty({d.numel}, torch::dtype(d.sign ? torch::kChar : torch::kByte).device(x.device()));

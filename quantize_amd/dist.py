@@ -27,42 +27,36 @@ def shard_batch(x, world_size=None, rank=None):
     return x[lo:hi]
 
 
-def gather_logits(logits, group=None):
+def gather_logits(logits, group=None, equal_shards=None):
     """All-gather per-rank (B_r, C) logits into the global (sum B_r, C) tensor, rank order = image
     order.  Equal shards use one all_gather_into_tensor (a single RCCL ncclAllGather); unequal
-    shards fall back to a padded gather."""
+    shards fall back to a padded gather.
+
+    equal_shards=True is the caller's promise that every rank holds the same number of rows (the bench:
+    256 images per rank) and skips the size exchange.  Otherwise the row counts are all-gathered on EVERY
+    call, so all ranks always take the same branch: a decision cached per rank (round 1) let two ranks issue
+    different collectives when the global batch changed between calls (7 then 8 images on 2 ranks: hang)."""
     world = dist.get_world_size(group)
     if world == 1:
         return logits
     logits = logits.contiguous()
-    sizes = torch.tensor([logits.shape[0]], device=logits.device, dtype=torch.int64)
-    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
-    if _equal_shards_hint(logits, group):
+    counts = None
+    if not equal_shards:
+        sizes = torch.tensor([logits.shape[0]], device=logits.device, dtype=torch.int64)
+        all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+        dist.all_gather(all_sizes, sizes, group=group)
+        counts = [int(s.item()) for s in all_sizes]
+    if counts is None or min(counts) == max(counts):
         out = torch.empty((world * logits.shape[0],) + tuple(logits.shape[1:]), dtype=logits.dtype,
                           device=logits.device)
         dist.all_gather_into_tensor(out, logits, group=group)
         return out
-    dist.all_gather(all_sizes, sizes, group=group)
-    counts = [int(s.item()) for s in all_sizes]
     m = max(counts)
     padded = torch.zeros((m,) + tuple(logits.shape[1:]), dtype=logits.dtype, device=logits.device)
     padded[: logits.shape[0]] = logits
     parts = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(parts, padded, group=group)
     return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
-
-
-_EQUAL = {}
-
-
-def _equal_shards_hint(logits, group):
-    """Decide once per (group, shape) whether every rank holds the same number of rows."""
-    key = (id(group), tuple(logits.shape), logits.dtype)
-    if key not in _EQUAL:
-        n = torch.tensor([logits.shape[0], -logits.shape[0]], device=logits.device, dtype=torch.int64)
-        dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
-        _EQUAL[key] = int(n[0].item()) == -int(n[1].item())
-    return _EQUAL[key]
 
 
 def top1(logits, targets=None):

@@ -51,14 +51,20 @@ def g6():
     return Golden("g6_linear_module.npz")
 
 
-def conv_tolerance(got, exact64, chain32):
-    """Parity rule for the fp32 conv result (after SURVEY.md section 7, "fp32-order parity"): the
-    reference accumulates K terms sequentially in fp32, so its own result is off the float64-exact
-    value by an amount that grows with |out| and K (1.4e-4 at K=4608, |out| rms 15).  The build must
-    be within 1e-5 abs of exact (north_star's bar, reachable when |out| is O(1)), or at least as close
-    to exact as the reference's fp32 chain is at its worst element on the same tensor (x2 headroom,
-    because the two fp32 evaluations round independently element by element)."""
+def conv_tolerance(got, exact64, *chains):
+    """Parity rule for the fp32 conv result ("fp32-order parity"), with no headroom factor:
+
+        |build - exact64| <= max(1e-5, max |reference fp32 chain - exact64|)
+
+    The reference accumulates K terms sequentially in fp32, so its own result is off the float64-exact value by an
+    amount that grows with |out| and K (1.4e-4 at K=4608, |out| rms 15).  `chains` are evaluations of the reference's
+    own arithmetic on the same inputs: the source as written (fp32 multiply then add), the same loop with the
+    multiply-add contracted (what nvcc emits by default), or the fp32 F.conv2d of the reference's packed forward in
+    the golden files.  The build has to be within 1e-5 abs of exact (north_star's bar), or as close to exact as the
+    worst of those legitimate reference results is on the same tensor."""
     err = np.abs(got.astype(np.float64) - exact64)
-    chain_err = np.abs(chain32.astype(np.float64) - exact64)
-    allowed = max(1e-5, 2.0 * float(chain_err.max())) if chain_err.size else 1e-5
+    allowed = 1e-5
+    for c in chains:
+        if c is not None and c.size:
+            allowed = max(allowed, float(np.abs(c.astype(np.float64) - exact64).max()))
     return err, allowed

@@ -44,7 +44,7 @@ def test_fuzz_vs_oracle(engine, seed):
         y, o32, o64 = _run_case(engine, case, via_capi=bool(k % 2))
         paths[case["path"]] += 1
         assert y.shape == o32.shape
-        _assert_conv_close(y, o64, o32, "seed %d case %d shape %s quant %s" % (seed, k, shp, (wb, wsgn, ab, asgn)))
+        _assert_conv_close(y, o64, o32, "seed %d case %d shape %s quant %s" % (seed, k, shp, (wb, wsgn, ab, asgn)), case["fma"])
         if case["path"] == 0:
             assert np.array_equal(y, case["fma"]), "generic path not bit-exact: seed %d case %d %s" % (seed, k, shp)
     assert paths[0] > 0 and paths[1] > 20

@@ -24,8 +24,8 @@ def _t(a, dtype=None):
     return t if dtype is None else t.to(dtype)
 
 
-def _assert_conv_close(got, exact64, chain32, what):
-    err, allowed = conv_tolerance(got, exact64, chain32)
+def _assert_conv_close(got, exact64, chain32, what, fma=None):
+    err, allowed = conv_tolerance(got, exact64, chain32, fma)
     bad = err > allowed
     assert not bad.any(), "%s: %d elements off, worst err %.3g (allowed %.3g)" % (
         what, int(bad.sum()), float(err.max()), allowed)
@@ -46,7 +46,17 @@ def test_g3_golden_cases(engine, g3):
                                    _t(g3.get(key, "x_scale")), _t(g3.get(key, "x_zero")), *w, bias, stride, pad)
         ref = g3.get(key, "exact64")
         assert y.dtype == torch.float32 and tuple(y.shape) == ref.shape and y.is_contiguous()
-        _assert_conv_close(y.cpu().numpy(), ref, g3.get(key, "chain32"), key)
+        # the golden chain32 is the reference's packed forward (blocked fp32 F.conv2d); the reference KERNEL's own
+        # sequential chain (oracle, as written and contracted) is the other legitimate fp32 evaluation
+        wargs = (g3.get(key, "w_packed"), g3.get(key, "w_des"), g3.get(key, "w_scale").reshape(-1),
+                 g3.get(key, "w_zero").reshape(-1), g3.get(key, "bias"), stride, pad)
+        if x is not None:
+            seq = [oracle.quantconv2d_float_input(x, *wargs, mode=m) for m in ("fp32", "fp32_fma")]
+        else:
+            seq = [oracle.quantconv2d(g3.get(key, "x_packed"), g3.get(key, "x_des"), g3.get(key, "x_scale").reshape(-1),
+                                      g3.get(key, "x_zero").reshape(-1), *wargs, mode=m) for m in ("fp32", "fp32_fma")]
+        err, allowed = conv_tolerance(y.cpu().numpy(), ref, g3.get(key, "chain32"), *seq)
+        assert not (err > allowed).any(), "%s: worst err %.3g (allowed %.3g)" % (key, float(err.max()), allowed)
 
 
 def test_g4_reference_module_capture(engine, g4):
@@ -177,7 +187,7 @@ def test_random_sweep_vs_oracle(engine, via_capi):
                                 zeros=k % 3 != 0, bias=k % 4 != 0)
             y, o32, o64 = _run_case(engine, case, via_capi)
             assert y.shape == o32.shape
-            _assert_conv_close(y, o64, o32, "shape %s quant %s" % (shp, (wb, wsgn, ab, asgn)))
+            _assert_conv_close(y, o64, o32, "shape %s quant %s" % (shp, (wb, wsgn, ab, asgn)), case["fma"])
             if case["path"] == 0:
                 # the generic kernel keeps the reference's ic->kh->kw fmaf order: bit-identical to the
                 # oracle's fused chain (padded taps add +0.0, which only differs for an exact -0.0 sum)
@@ -270,7 +280,7 @@ def test_kernel_variants_forced_by_env(engine, env):
             for zeros in (False, True):
                 case = _random_case(rng, *shp, 8, 1, 8, 0 if zeros else 1, w_pc=True, a_pc=False, zeros=zeros, bias=True)
                 y, o32, o64 = _run_case(engine, case, via_capi=True)
-                _assert_conv_close(y, o64, o32, "%s %s zeros=%s" % (env, shp, zeros))
+                _assert_conv_close(y, o64, o32, "%s %s zeros=%s" % (env, shp, zeros), case["fma"])
     finally:
         for k, v in old.items():
             if v is None:
@@ -295,7 +305,7 @@ def test_sub8_activation_paths(engine, expand):
                     case = _random_case(rng, *shp, wb, wsgn, ab, asgn, w_pc=True, a_pc=False, zeros=zeros, bias=True)
                     y, o32, o64 = _run_case(engine, case, via_capi=True)
                     assert case["path"] == 1
-                    _assert_conv_close(y, o64, o32, "expand=%s %s %s zeros=%s" % (expand, shp, (wb, wsgn, ab, asgn), zeros))
+                    _assert_conv_close(y, o64, o32, "expand=%s %s %s zeros=%s" % (expand, shp, (wb, wsgn, ab, asgn), zeros), case["fma"])
     finally:
         if old is None:
             os.environ.pop("QE_EXPAND", None)
@@ -314,4 +324,77 @@ def test_4bit_weights_on_flat_kernels(engine):
                 case = _random_case(rng, *shp, wb, wsgn, ab, asgn, w_pc=True, a_pc=False, zeros=zeros, bias=True)
                 y, o32, o64 = _run_case(engine, case, via_capi=True)
                 assert case["path"] == 1
-                _assert_conv_close(y, o64, o32, "w4 %s %s zeros=%s" % (shp, (wb, wsgn, ab, asgn), zeros))
+                _assert_conv_close(y, o64, o32, "w4 %s %s zeros=%s" % (shp, (wb, wsgn, ab, asgn), zeros), case["fma"])
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE config 1: ResNet-18 on CIFAR-10 (32x32 inputs, torchvision stem: conv1 7x7/2 pad 3 + maxpool).
+# The reference runs it through runner/ptq.py on CPU; its conv shapes are exercised here on the HIP engine
+# against the oracle.  (IC, OC, K, stride, pad, H) of every distinct conv of the network.
+# ---------------------------------------------------------------------------------------------
+RESNET18_CIFAR = [
+    (3, 64, 7, 2, 3, 32),                                   # conv1 on a 32x32 image -> 16x16 (maxpool -> 8x8)
+    (64, 64, 3, 1, 1, 8),                                   # layer1: 4 convs
+    (64, 128, 3, 2, 1, 8), (128, 128, 3, 1, 1, 4), (64, 128, 1, 2, 0, 8),      # layer2 (+ downsample)
+    (128, 256, 3, 2, 1, 4), (256, 256, 3, 1, 1, 2), (128, 256, 1, 2, 0, 4),    # layer3
+    (256, 512, 3, 2, 1, 2), (512, 512, 3, 1, 1, 1), (256, 512, 1, 2, 0, 2),    # layer4: 3x3 on 2x2 and 1x1 planes
+]
+
+
+@pytest.mark.parametrize("bits", [(8, 8), (4, 4)])
+def test_resnet18_cifar_conv_table(engine, bits):
+    """Every conv shape of ResNet-18 at CIFAR resolution (8x8, 4x4, 2x2 and 1x1 planes, 1x1/2 downsamples), W8A8 and
+    W4A4, symmetric (the reference's default) and asymmetric operands, batch 5 (a partial image group on the
+    small-plane kernels), against the oracle; W8A8 symmetric additionally at north_star's plain 1e-5."""
+    wb, ab = bits
+    rng = np.random.RandomState(1800 + wb)
+    for (IC, OC, K, s, p, H) in RESNET18_CIFAR:
+        for zeros in (False, True):
+            case = _random_case(rng, 5, IC, H, H, OC, K, s, p, wb, 1, ab, 0 if zeros else 1, w_pc=True, a_pc=False,
+                                zeros=zeros, bias=True)
+            y, o32, o64 = _run_case(engine, case, via_capi=True)
+            assert y.shape == o32.shape
+            _assert_conv_close(y, o64, o32, "rn18 %s W%dA%d zeros=%s" % ((IC, OC, K, s, p, H), wb, ab, zeros), case["fma"])
+            if wb == 8 and not zeros:
+                assert np.abs(y.astype(np.float64) - o64).max() <= 1e-5, (IC, OC, K, s, p, H)
+
+
+def test_resnet50_conv1_at_224(engine):
+    """The stem at its real size: (1, 3, 224, 224) -> (1, 64, 112, 112), 7x7/2 pad 3, vs the oracle (seconds)."""
+    rng = np.random.RandomState(224)
+    for zeros in (False, True):
+        case = _random_case(rng, 1, 3, 224, 224, 64, 7, 2, 3, 8, 1, 8, 0 if zeros else 1, w_pc=True, a_pc=False,
+                            zeros=zeros, bias=True)
+        y, o32, o64 = _run_case(engine, case, via_capi=True)
+        assert y.shape == (1, 64, 112, 112) and case["path"] == 1
+        _assert_conv_close(y, o64, o32, "conv1@224 zeros=%s" % zeros, case["fma"])
+        if not zeros:
+            assert np.abs(y.astype(np.float64) - o64).max() <= 1e-5
+
+
+# one layer per kernel family of the headline stack (stem, flat 56/28/14, flat stride 2, gather + flat, small-plane
+# flat, 3x3 at 56/28/14/7 incl. stride 2): the batch-256 launch must give every image the result it gets alone
+FAMILY_LAYERS = [(3, 64, 7, 2, 3, 224), (256, 64, 1, 1, 0, 56), (64, 64, 3, 1, 1, 56), (256, 512, 1, 2, 0, 56),
+                 (128, 128, 3, 2, 1, 56), (512, 128, 1, 1, 0, 28), (128, 128, 3, 1, 1, 28), (512, 1024, 1, 2, 0, 28),
+                 (256, 256, 3, 2, 1, 28), (1024, 256, 1, 1, 0, 14), (256, 1024, 1, 1, 0, 14), (1024, 2048, 1, 2, 0, 14),
+                 (2048, 512, 1, 1, 0, 7), (512, 2048, 1, 1, 0, 7), (512, 512, 3, 1, 1, 7)]
+
+
+def test_batch_independence_every_kernel_family(engine):
+    g = torch.Generator(device=DEV)
+    g.manual_seed(77)
+    N = 256
+    for (IC, OC, K, s, p, H) in FAMILY_LAYERS:
+        qx = torch.randint(-128, 128, (N, IC, H, H), generator=g, device=DEV, dtype=torch.int8)
+        qw = torch.randint(-128, 128, (OC, IC, K, K), generator=g, device=DEV, dtype=torch.int8)
+        sw = torch.rand(OC, generator=g, device=DEV) * 5e-4 + 2.5e-4
+        sx, z1, zc = torch.full((1,), 2e-3, device=DEV), torch.zeros(1, device=DEV), torch.zeros(OC, device=DEV)
+        bias = torch.randn(OC, generator=g, device=DEV) * 0.1
+        xp, xd = engine.tpack(qx, 8, True)
+        wp, wd = engine.tpack(qw, 8, True)
+        y = engine.quantconv2d(xp, xd, sx, z1, wp, wd, sw, zc, bias, s, p)
+        for n in (0, 129, 255):
+            xp1, xd1 = engine.tpack(qx[n:n + 1].contiguous(), 8, True)
+            y1 = engine.quantconv2d(xp1, xd1, sx, z1, wp, wd, sw, zc, bias, s, p)
+            assert torch.equal(y[n:n + 1], y1), (IC, OC, K, s, H, n)
+        del qx, y, xp

@@ -23,8 +23,8 @@ def _t(a, dtype=None):
     return t if dtype is None else t.to(dtype)
 
 
-def _close(got, exact64, chain32, what):
-    err, allowed = conv_tolerance(got, exact64, chain32)
+def _close(got, exact64, chain32, what, fma=None):
+    err, allowed = conv_tolerance(got, exact64, chain32, fma)
     bad = err > allowed
     assert not bad.any(), "%s: %d elements off, worst err %.3g (allowed %.3g)" % (
         what, int(bad.sum()), float(err.max()), allowed)
@@ -53,7 +53,9 @@ def test_g5_golden_cases(engine, g5):
                 assert np.array_equal(y.cpu().numpy(), g5.get(key, "chain32_fma")), key
         ref = g5.get(key, "exact64")
         assert y.dtype == torch.float32 and tuple(y.shape) == ref.shape and y.is_contiguous()
-        _close(y.cpu().numpy(), ref, g5.get(key, "chain32"), key)
+        # chain32 = the reference module's packed forward (fp32 F.linear); chain32_fma = the reference kernel's own
+        # k-sequential chain (oracle) -- both are legitimate fp32 evaluations of the reference
+        _close(y.cpu().numpy(), ref, g5.get(key, "chain32"), key, g5.get(key, "chain32_fma"))
     assert paths == {0, 1}      # both the MFMA GEMM and the fp32 kernel were exercised
 
 
@@ -139,7 +141,7 @@ def test_random_sweep_vs_oracle(engine, via_capi):
             torch.cuda.synchronize()
             got = y.cpu().numpy()
             assert got.shape == c["o32"].shape
-            _close(got, c["o64"], c["o32"], "shape %s quant %s" % (shp, (wb, wsgn, ab, asgn)))
+            _close(got, c["o64"], c["o32"], "shape %s quant %s" % (shp, (wb, wsgn, ab, asgn)), c["fma"])
             if path == 0:
                 assert np.array_equal(got, c["fma"]), "fp32 kernel not bit-exact: %s %s" % (shp, (wb, wsgn, ab, asgn))
             else:
@@ -155,7 +157,8 @@ def test_vit_shapes_and_row_independence(engine):
         c = _random_case(rng, 197, K, O, 8, 1, 8, 1, w_pc=True, a_pr=False, zeros=False, bias=True)
         y, path = _run(engine, c, True)
         assert path == 1
-        assert np.abs(y.cpu().numpy().astype(np.float64) - c["o64"]).max() <= 1e-5 * max(1.0, float(np.abs(c["o64"]).max()))
+        # north_star's bar is ABSOLUTE 1e-5 at the headline operand scales (s_x = 2e-3, s_w ~ 5e-4: |out| is O(1))
+        assert np.abs(y.cpu().numpy().astype(np.float64) - c["o64"]).max() <= 1e-5, (K, O)
     B, K, O = 256 * 197, 768, 768
     g = torch.Generator(device=DEV)
     g.manual_seed(1)

@@ -110,7 +110,7 @@ def test_g4_module_capture(g4):
 
     The modules use (q + zero) * scale (quantizer.py:218), the kernels (q - zero) * scale
     (quantconv2d.cu:113-115): zeros are negated at this boundary."""
-    assert len(g4.index) == 4
+    assert len(g4.index) == 9
     for key in g4.index:
         qx = g4.get(key, "qx")
         a_bits, a_sign = [int(v) for v in g4.get(key, "a_bits_sign")]

@@ -35,7 +35,9 @@ if nf and nw:
     # KiB units; gfx950 FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced reads -> doubled
     fetch_b = 2.0 * fs * 1024 / nf
     write_b = ws * 1024 / nw
-    d = {"tag": tag, "launches_profiled": nf, "fetch_size_kib_per_launch_raw": fs / nf, "write_size_kib_per_launch": ws / nw,
+    sys.path.insert(0, os.getcwd())
+    from quantize_amd.build import source_sha16
+    d = {"tag": tag, "source_sha16": source_sha16(), "launches_profiled": nf, "fetch_size_kib_per_launch_raw": fs / nf, "write_size_kib_per_launch": ws / nw,
          "fetch_bytes_per_launch_corrected_x2": fetch_b, "write_bytes_per_launch": write_b,
          "hbm_bytes_per_launch": fetch_b + write_b,
          "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE) over python bench.py --steps 5 --warmup 2; conv_mfma_* kernels only; "
