@@ -1,0 +1,477 @@
+// qe_conv_flatd.hip -- 1x1 / stride 1 / pad 0 quantconv2d as a GEMM whose operand stages arrive by LDS-DMA ("flatd").
+//
+// Replaces the per-element loop of quantconv2d_cuda_kernel (engine/kernels/functions/quantconv2d.cu:78-141) for
+// 8-bit x 8-bit 1x1 layers with IC % 64 == 0.  Same arithmetic as conv_mfma_flat_kernel (qe_conv_mfma_kernel.hpp):
+//   out[n,oc,p] = bias[oc] + sx sw[oc] ( S_aw - zw' S_x - zx' S_w + IC zx' zw' ),  a = u ^ 0x80, S_aw on
+//   v_mfma_i32_32x32x32_i8 with A = activations (rows = pixels, fragments by ds_read_b64_tr_b8 from the native
+//   [channel][pixel] order), B = weights (cols = output channel, 16 contiguous bytes of the packed OIHW row).
+// What differs is how the operands reach LDS.  The register-staged flat kernel keeps ONE stage of loads in flight per
+// workgroup (its staging registers), and a layer with a long K loop and small planes (1024->256 @14x14, 2048->512 @7x7)
+// pays one memory round trip per stage: 2.8 TB/s and 1.0 TB/s in the ResNet-50 stack, bound by neither HBM nor MFMA.
+// Here both operands of a 64-channel stage are written into a ring of 3 LDS buffers by global_load_lds_dwordx4 (no
+// staging registers, nothing to transpose or convert on the way), two stages ahead of the MFMAs, with one raw
+// s_barrier and a counted vmcnt per stage (a __syncthreads() would drain the DMA queue).  The u ^ 0x80 recode moves to
+// the fragments.
+//
+// LDS image of the activations = what ds_read_b64_tr_b8 wants: rows = channels, 16-pixel groups at 8-byte aligned
+// addresses, row stride an odd multiple of 32 B (conflict-free).  LDS-DMA writes lane-linear 16-byte slots, but the
+// GLOBAL address is per lane, so slot (channel c, j) simply fetches plane bytes [16 j, 16 j + 16) of channel c:
+//   WIDE  (planes >= 160 pixels; tile = 32 NT pixels of one plane, NT = 5 | 7): row stride 32 NT bytes, 2 NT slots per row;
+//         a 14x14 plane (196 B) is one 224-pixel tile whose rows start 4-byte aligned in global memory -- LDS-DMA takes
+//         that (tools/probe_dma_align.hip) -- and whose last 28 bytes per row are the next channel's (never stored);
+//   SMALL (planes <= 64 pixels: 7x7; tile = 4 whole images x 2 column tiles): 64-byte rows [image][channel][64], byte-aligned
+//         sources, slot position XOR 2 for channels with bit 2 set so that the 8 rows x 2 pixel groups of a transposed read
+//         cover all 64 banks once.
+// The only bytes such slots could read past the tensor are those behind the LAST plane of the LAST image when the plane
+// size is not a multiple of 16: pure-garbage slots fetch the tensor's last 16 bytes instead, and the one slot that is
+// partly valid is left out of the DMA (lane masked off) and written by its thread from a register.
+#include "qe_conv_mfma_kernel.hpp"
+
+#include <cstdlib>
+#include <utility>
+
+namespace qe {
+
+struct FlatdArgs {
+    const uint8_t *x;          // [N][IC][P] stored codes, 8-bit
+    const uint8_t *w;          // [OC][IC] stored codes, 8-bit
+    const float *x_scale, *x_zero, *w_scale, *w_zero, *bias;
+    int x_sign, w_sign, w_per_tensor;
+    float *out;                // [N][OC][P] fp32
+    int N, IC, OC, P;
+    int tiles_per_image;       // WIDE: pixel tiles per plane; SMALL: unused
+    int n_pix_tiles, n_oc_tiles, chunk;
+    int dbg;                   // tuning experiments (QE_FLATD_DBG): 1 = no output stores, 2 = no K loop (stores only), 4 = no MFMA phase
+};
+
+constexpr int FD_CK = 64;              // channels per stage
+constexpr int FD_RING = 3;
+constexpr int FD_MT = 128;             // output channels per workgroup (4 waves x 32)
+constexpr int FD_WBYTES = FD_MT * FD_CK;
+
+template <int NT, bool SMALL> struct FdGeom {
+    static constexpr int RS = SMALL ? 64 : 32 * NT;                  // LDS bytes per channel row (WIDE: NT odd)
+    static constexpr int XBYTES = SMALL ? 4 * FD_CK * 64 : FD_CK * RS;
+    static constexpr int STAGE = XBYTES + FD_WBYTES;
+    static constexpr int XINSTR = XBYTES / 1024;                     // wave-level DMA instructions per stage
+    static constexpr int NTP = 32 * NT;
+    static constexpr int PATCH = SMALL ? 4 * 32 * 49 * 4 : 4 * 32 * 36 * 4;
+    static constexpr int RING_BYTES = FD_RING * STAGE > PATCH ? FD_RING * STAGE : PATCH;
+    static constexpr int LDS = RING_BYTES + 4 * NTP * 4 /* S_x, one copy per wave */;
+};
+
+// Transposed LDS reads as inline asm.  hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of every
+// __builtin_amdgcn_ds_read_tr8_b64 that follows an LDS-DMA (the builtin's memory operand carries no alias information,
+// so the wait-count pass assumes it may read what the DMA writes), which drained the two stages in flight on every
+// stage.  The ring protocol (counted vmcnt + barrier) already orders reads behind the DMA that fills their slot; these
+// reads are invisible to that pass, so their own lgkmcnt waits are written by hand (tr8_wait).
+template <int OFF>
+__device__ __forceinline__ v2i tr8_read(uint32_t lds_addr)
+{
+    v2i r;
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=&v"(r) : "v"(lds_addr), "n"(OFF));
+    return r;
+}
+__device__ __forceinline__ v4i lds_read_b128_asm(uint32_t lds_addr)
+{
+    v4i r;
+    asm volatile("ds_read_b128 %0, %1" : "=&v"(r) : "v"(lds_addr));
+    return r;
+}
+// wait until at most N LDS operations of this wave are outstanding; the fragments are tied through the statement so
+// that nothing reading them can be scheduled above it
+__device__ __forceinline__ void tie_wf(v4i &w0, v4i &w1) { asm volatile("" : "+v"(w0), "+v"(w1)); }
+template <int N, int NT>
+__device__ __forceinline__ void tr8_wait(v2i (&lo)[NT], v2i (&hi)[NT])
+{
+    static_assert(NT == 5 || NT == 7 || NT == 8, "");
+    if constexpr (NT == 5)
+        asm volatile("s_waitcnt lgkmcnt(%10)" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]),
+                     "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]) : "n"(N));
+    else if constexpr (NT == 7)
+        asm volatile("s_waitcnt lgkmcnt(%14)" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]),
+                     "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]) : "n"(N));
+    else
+        asm volatile("s_waitcnt lgkmcnt(%16)" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]),
+                     "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]), "+v"(hi[7]) : "n"(N));
+}
+// all fragment reads of 32-channel chunk K of a stage: tile T at LDS offset K*32*RS + ..., the second 8 channels 8 rows on
+template <int K, int RS, bool SMALL, int NT, int... T>
+__device__ __forceinline__ void tr8_chunk(std::integer_sequence<int, T...>, uint32_t base0, uint32_t base1, v2i (&lo)[NT], v2i (&hi)[NT])
+{
+    if constexpr (SMALL)   // tile T = image T/2, column tile T%2 (its slot position differs by XOR 2: second base)
+        ((lo[T] = tr8_read<K * 32 * 64 + (T >> 1) * (FD_CK * 64)>((T & 1) ? base1 : base0),
+          hi[T] = tr8_read<K * 32 * 64 + (T >> 1) * (FD_CK * 64) + 8 * 64>((T & 1) ? base1 : base0)), ...);
+    else
+        ((lo[T] = tr8_read<K * 32 * RS + T * 32>(base0), hi[T] = tr8_read<K * 32 * RS + T * 32 + 8 * RS>(base0)), ...);
+}
+
+template <int NT, bool SMALL>
+__global__ __launch_bounds__(256, 2) void conv_flatd_kernel(const FlatdArgs a)
+{
+    using G = FdGeom<NT, SMALL>;
+    constexpr int RS = G::RS;
+    static_assert(SMALL || (NT & 1) == 1, "WIDE tiles need an odd tile count (row stride = odd multiple of 32 B)");
+    static_assert(!SMALL || NT == 8, "SMALL tiles are 4 images x 2 column tiles");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, h = lane >> 5;
+    const int P = a.P;
+
+    // ---- tile decode: XCD-aware block map (same scheme as block_to_tile of the register-staged kernels) -------
+    int pt, ot;
+    {
+        const int bid = blockIdx.x;
+        const int idx = bid >> 3;
+        const int j = idx / a.n_oc_tiles;
+        ot = idx - j * a.n_oc_tiles;
+        const int c = j / a.chunk;
+        pt = (c * 8 + (bid & 7)) * a.chunk + (j - c * a.chunk);
+    }
+    if (pt >= a.n_pix_tiles) return;
+    int n0, p0;
+    if constexpr (SMALL) { n0 = pt * 4; p0 = 0; }
+    else { n0 = pt / a.tiles_per_image; p0 = (pt - n0 * a.tiles_per_image) * G::NTP; }
+
+    // ---- epilogue constants of this lane's output channel ------------------------------------------------------
+    const int oc = ot * FD_MT + wave * 32 + col;
+    const int occ = oc < a.OC ? oc : a.OC - 1;
+    const float sw = a.w_per_tensor ? a.w_scale[0] : a.w_scale[occ];
+    const float zwp = (a.w_per_tensor ? a.w_zero[0] : a.w_zero[occ]) - (a.w_sign ? 0.0f : 128.0f);
+    const float alpha = a.x_scale[0] * sw;
+    const float bia = a.bias ? a.bias[occ] : 0.0f;
+    const float zxp = a.x_zero[0] - (a.x_sign ? 0.0f : 128.0f);
+
+    // ---- DMA sources (stage 0; a stage advances X by 64 planes and W by 64 bytes) ------------------------------
+    // X: LDS slot e = 64 * (wave-instruction q) + lane, q = wave, wave + 4, ...
+    constexpr int PXW = (G::XINSTR + 3) / 4;          // X instructions of waves 0 .. (XINSTR % 4) - 1 (the others issue one less)
+    const int n_xi = (G::XINSTR % 4 == 0 || wave < G::XINSTR % 4) ? PXW : PXW - 1;
+    const int64_t x_last16 = (int64_t)a.N * a.IC * P - 16;      // last address a 16-byte read may start at
+    const uint8_t *px[PXW];
+    int fix_lds = -1, fix_i = -1;                      // this thread writes the tensor's last bytes itself (last stage only)
+    uint32_t fix_val = 0;
+#pragma unroll
+    for (int i = 0; i < PXW; ++i) {
+        const int e = 64 * (wave + 4 * i) + lane;
+        int64_t src;
+        bool last_row;
+        int j;
+        if constexpr (SMALL) {
+            const int img = e >> 8, c = (e >> 2) & 63, jj = e & 3;
+            j = jj ^ (2 * ((c >> 2) & 1));
+            const int n = n0 + img < a.N ? n0 + img : a.N - 1;
+            src = ((int64_t)n * a.IC + c) * P + 16 * j;
+            last_row = (n0 + img == a.N - 1) && c == FD_CK - 1;
+        } else {
+            const int c = e / (RS / 16);
+            j = e - c * (RS / 16);
+            src = ((int64_t)n0 * a.IC + c) * P + p0 + 16 * j;
+            last_row = (n0 == a.N - 1) && c == FD_CK - 1;
+        }
+        // stage s adds s * 64 planes: only the last stage of the last image can run past the tensor
+        const int64_t lim = x_last16 - (int64_t)(a.IC - FD_CK) * P;
+        if (last_row && src > lim) {
+            const int pos = (SMALL ? 0 : p0) + 16 * j;            // first plane byte this slot should hold
+            if (pos < P && e < G::XBYTES / 16) {
+                // partly valid (P - pos = 4 or 1 bytes): in the last stage this lane is masked out of the DMA (see
+                // issue()) and stores the valid bytes itself; in every earlier stage the slot is an ordinary in-bounds
+                // read, so its address stays as it is
+                fix_lds = e * 16;
+                fix_i = i;
+                uint32_t v = 0;
+                const uint8_t *tail = a.x + (int64_t)a.N * a.IC * P - (P - pos);
+                for (int b = 0; b < 4 && b < P - pos; ++b) v |= (uint32_t)tail[b] << (8 * b);
+                fix_val = v;
+            } else {
+                src = lim;                                         // pure garbage slot: any valid 16 bytes will do, in every stage
+            }
+        }
+        px[i] = a.x + src;
+    }
+    // W: slot e = tid + 256 i <-> row e >> 2 of the tile, position e & 3 holds k-piece (e & 3) ^ ((row >> 2) & 3)
+    const uint8_t *pw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + 256 * i;
+        const int r = e >> 2, sl = e & 3;
+        const int orow = ot * FD_MT + r < a.OC ? ot * FD_MT + r : a.OC - 1;
+        pw[i] = a.w + (int64_t)orow * a.IC + 16 * (sl ^ ((r >> 2) & 3));
+    }
+    const int64_t x_step = (int64_t)FD_CK * P;
+    const int n_stages = (a.dbg & 2) ? 0 : a.IC / FD_CK;
+    auto issue = [&](int s) __attribute__((always_inline)) {
+        uint8_t *buf = smem + (s % FD_RING) * G::STAGE;
+        // the one slot that would read past the tensor (last stage of the last plane) is left out of the DMA: its lane is
+        // masked off and writes the valid bytes with a plain LDS store before the stage's barrier (a store issued after
+        // `s_waitcnt vmcnt(0)` on top of a DMA'd slot was observed to lose against the DMA's own LDS write)
+        const int skip = (s == n_stages - 1) ? fix_i : -1;
+#pragma unroll
+        for (int i = 0; i < PXW; ++i) {
+            if (i < n_xi && i != skip && !(a.dbg & 16))    // first term wave-uniform, second per lane (EXEC mask)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(px[i] + s * x_step),
+                                                 (__attribute__((address_space(3))) void *)(buf + 1024 * (wave + 4 * i)), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (!(a.dbg & 8))
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pw[i] + s * FD_CK),
+                                             (__attribute__((address_space(3))) void *)(buf + G::XBYTES + (256 * i + 64 * wave) * 16), 16, 0, 0);
+    };
+
+    if (n_stages > 0) issue(0);
+    if (n_stages > 1) issue(1);
+
+    // S_x (per-pixel channel sums) is only needed by output channels with zw' != 0: decided per WAVE (its 32 channels),
+    // so the prologue needs no workgroup barrier (a __syncthreads() here would drain the two stages just requested)
+    const bool need_sx = __builtin_amdgcn_ballot_w64(oc < a.OC && zwp != 0.0f) != 0ull;
+    int *sxp = reinterpret_cast<int *>(smem + G::RING_BYTES) + wave * G::NTP;
+
+    v16i acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0;
+    int swacc = 0;
+    int sxacc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sxacc[t] = 0;
+
+    // fragment addressing (32-bit LDS byte addresses for the hand-written transposed reads)
+    const int i16 = lane & 15;
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
+    uint32_t tr_b0, tr_b1;
+    if constexpr (SMALL) {
+        // row (16 h + i16/2) of [image][channel][64]; logical slot 2 tt + (lane>>4)&1 sits at position slot ^ 2 for rows 4-7
+        const int sm_sl = ((lane >> 4) & 1) ^ (2 * (i16 >> 3));
+        const uint32_t rowb = (uint32_t)((16 * h + (i16 >> 1)) * 64 + 8 * (i16 & 1));
+        tr_b0 = rowb + 16u * (uint32_t)sm_sl;
+        tr_b1 = rowb + 16u * (uint32_t)(sm_sl ^ 2);
+    } else {
+        tr_b0 = (uint32_t)((16 * h + (i16 >> 1)) * RS + 16 * ((lane >> 4) & 1) + 8 * (i16 & 1));
+        tr_b1 = tr_b0;
+    }
+    const int wf_base = G::XBYTES + (wave * 32 + col) * FD_CK;
+    const int wswz = (col >> 2) & 3;
+
+    auto main_loop = [&](auto sx_tag) __attribute__((always_inline)) {
+        constexpr bool SX = decltype(sx_tag)::value;
+        for (int s = 0; s < n_stages; ++s) {
+            // stage s has landed for this wave once at most the pieces of stage s + 1 are still outstanding
+            if ((a.dbg & 24) && s + 1 < n_stages) {
+                const int n = ((a.dbg & 16) ? 0 : n_xi) + ((a.dbg & 8) ? 0 : 2);   // experiments: pieces of one stage
+                switch (n) {
+                    case 0: __builtin_amdgcn_s_waitcnt(0x0f70); break;
+                    case 2: __builtin_amdgcn_s_waitcnt(0x0f72); break;
+                    case 3: __builtin_amdgcn_s_waitcnt(0x0f73); break;
+                    case 4: __builtin_amdgcn_s_waitcnt(0x0f74); break;
+                    default: __builtin_amdgcn_s_waitcnt(0x0f70); break;
+                }
+            } else if (s + 1 < n_stages) {
+                if (n_xi == PXW) __builtin_amdgcn_s_waitcnt(0x0f70 | (PXW + 2)); else __builtin_amdgcn_s_waitcnt(0x0f70 | (PXW + 1));
+            } else {
+                __builtin_amdgcn_s_waitcnt(0x0f70);
+                if (fix_lds >= 0) {
+                    uint8_t *dst = smem + (s % FD_RING) * G::STAGE + fix_lds;
+                    if constexpr (SMALL) *dst = (uint8_t)fix_val; else *reinterpret_cast<uint32_t *>(dst) = fix_val;
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                }
+            }
+            __builtin_amdgcn_s_barrier();             // ... for every wave; and ring slot (s + 2) % 3 has no reader left
+            if (s + 2 < n_stages) issue(s + 2);
+            if (a.dbg & 4) continue;                  // experiment: DMA ring only, no fragment reads / MFMA
+            // all fragment reads of the stage are requested up front (2 x NT x 2 <= 32 reads, returned in order), the
+            // MFMAs of chunk 0 run while chunk 1's reads are still arriving
+            const uint32_t xb = smem_lds + (uint32_t)((s % FD_RING) * G::STAGE);
+            v2i lo0[NT], hi0[NT], lo1[NT], hi1[NT];
+            v4i wf[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) wf[k] = lds_read_b128_asm(xb + (uint32_t)(wf_base + 16 * ((2 * k + h) ^ wswz)));
+            tr8_chunk<0, RS, SMALL>(std::make_integer_sequence<int, NT>{}, xb + tr_b0, xb + tr_b1, lo0, hi0);
+            tr8_chunk<1, RS, SMALL>(std::make_integer_sequence<int, NT>{}, xb + tr_b0, xb + tr_b1, lo1, hi1);
+            // LDS operations return in order: once at most the 2 NT reads of chunk 1 are outstanding, the weight fragments
+            // and chunk 0 have arrived (the counter saturates at 15: for 16 reads the wait is simply a little early)
+            if constexpr (2 * NT <= 15) tr8_wait<2 * NT>(lo0, hi0); else tr8_wait<15>(lo0, hi0);
+            tie_wf(wf[0], wf[1]);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    wf[k][j] ^= (int)0x80808080;      // u - 128: signed q, or unsigned q - 128
+                    swacc = __builtin_amdgcn_sdot4(wf[k][j], 0x01010101, swacc, false);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                v4i xf = {lo0[t][0], lo0[t][1], hi0[t][0], hi0[t][1]};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xf[j] ^= (int)0x80808080;
+                if constexpr (SX) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sxacc[t] = __builtin_amdgcn_sdot4(xf[j], 0x01010101, sxacc[t], false);
+                }
+                acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xf, wf[0], acc[t], 0, 0, 0);
+            }
+            tr8_wait<0>(lo1, hi1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                v4i xf = {lo1[t][0], lo1[t][1], hi1[t][0], hi1[t][1]};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xf[j] ^= (int)0x80808080;
+                if constexpr (SX) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sxacc[t] = __builtin_amdgcn_sdot4(xf[j], 0x01010101, sxacc[t], false);
+                }
+                acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xf, wf[1], acc[t], 0, 0, 0);
+            }
+        }
+    };
+    if (need_sx) main_loop(std::true_type{}); else main_loop(std::false_type{});
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------
+    const int sw_sum = swacc + __shfl_xor(swacc, 32);
+    const float cst = fmaf((float)a.IC * zxp, zwp, -zxp * (float)sw_sum);
+    if (need_sx) {
+        // S_x lives on the lane that owns the pixel as an A row; the accumulators have the pixel on the register:
+        // through this wave's own LDS copy (written and read by the same wave)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int v = sxacc[t] + __shfl_xor(sxacc[t], 32);
+            if (h == 0) sxp[32 * t + col] = v;
+        }
+    }
+    __syncthreads();          // every wave is done with the ring (it becomes the store patches)
+    if (a.dbg & 1) return;
+    if constexpr (!SMALL) {
+        // each wave turns its 32 oc x 32 px tiles through a private patch: one global_store_dwordx4 = 8 rows x 128 B
+        const int NTv = min(G::NTP, P - p0);
+        float *out_w = a.out + ((int64_t)n0 * a.OC + ot * FD_MT + wave * 32) * P + p0;
+        float *patch = reinterpret_cast<float *>(smem) + wave * (32 * 36);
+        const int rrow = lane >> 3, rq = lane & 7;
+        const uint32_t voff = (uint32_t)rrow * (uint32_t)P + 4u * (uint32_t)rq;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int q0 = t * 32;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float f = (float)acc[t][4 * gq + j] + cst;
+                    if (need_sx) f = fmaf(-zwp, (float)sxp[q0 + 8 * gq + 4 * h + j], f);
+                    v[j] = fmaf(alpha, f, bia);
+                }
+                *reinterpret_cast<float4 *>(patch + col * 36 + 8 * gq + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            const bool px_ok = q0 + 4 * rq < NTv;
+            if (q0 + 32 <= NTv && ot * FD_MT + wave * 32 + 32 <= a.OC) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 o4 = *reinterpret_cast<const float4 *>(patch + (8 * i + rrow) * 36 + 4 * rq);
+                    *reinterpret_cast<float4 *>(out_w + (int64_t)(8 * i) * P + q0 + voff) = o4;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 8 * i + rrow;
+                    const float4 o4 = *reinterpret_cast<const float4 *>(patch + row * 36 + 4 * rq);
+                    if (px_ok && ot * FD_MT + wave * 32 + row < a.OC)
+                        *reinterpret_cast<float4 *>(out_w + (int64_t)(8 * i) * P + q0 + voff) = o4;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+        }
+    } else {
+        // a wave's 32 channels x P pixels of one image are ONE contiguous, 16-byte aligned run of the output
+        // ((n OC + oc0) P floats, oc0 % 32 == 0, OC % 4 == 0): the patch is laid out exactly like it and copied flat.
+        float *patch = reinterpret_cast<float *>(smem) + wave * (32 * 49);
+        const int oc0 = ot * FD_MT + wave * 32;
+        const int vrows = min(32, a.OC - oc0);                    // <= 0: nothing to store
+        const int nfl = vrows > 0 ? vrows * P : 0;                // floats of the run
+        const bool vec_ok = (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pxl = 32 * tt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    float f = (float)acc[2 * gi + tt][r] + cst;
+                    if (need_sx) f = fmaf(-zwp, (float)sxp[64 * gi + pxl], f);
+                    if (pxl < P) patch[col * P + pxl] = fmaf(alpha, f, bia);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (n0 + gi < a.N) {
+                float *dst = a.out + ((int64_t)(n0 + gi) * a.OC + oc0) * P;
+                for (int i = lane; 4 * i < nfl; i += 64) {
+                    if (vec_ok && 4 * i + 4 <= nfl) *reinterpret_cast<float4 *>(dst + 4 * i) = *reinterpret_cast<const float4 *>(patch + 4 * i);
+                    else for (int b = 4 * i; b < nfl && b < 4 * i + 4; ++b) dst[b] = patch[b];
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+// tile variant: 0 = none, 5 / 7 = WIDE with that many column tiles, 8 = SMALL
+int flatd_variant(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w)
+{
+    if (sh->KH != 1 || sh->KW != 1 || sh->stride != 1 || sh->padding != 0) return 0;
+    if (x->n_bits != 8 || w->n_bits != 8 || x->n_param != 1) return 0;
+    if (sh->IC % FD_CK != 0 || sh->IC < 2 * FD_CK || sh->OC < 1 || sh->N < 1) return 0;
+    const int64_t P = (int64_t)sh->H * sh->W;
+    if ((int64_t)sh->N * sh->IC * P < 16 || (int64_t)sh->OC * P >= (1ll << 29) || (int64_t)sh->IC * P >= (1ll << 31)) return 0;
+    if ((reinterpret_cast<uintptr_t>(w->data) & 15) != 0) return 0;      // weight rows are fetched as aligned 16-byte pieces
+    if (P == 49 && sh->OC % 4 == 0 && (reinterpret_cast<uintptr_t>(x->data) & 15) == 0) return 8;
+    if ((P % 16 != 0 && P % 16 != 4) || P < 160) return 0;     // a row's last slot holds 16 or 4 valid bytes
+    if ((reinterpret_cast<uintptr_t>(x->data) & 3) != 0) return 0;
+    auto waste = [&](int t) { return (double)((P + 32 * t - 1) / (32 * t)) * (32 * t) / (double)P; };
+    return waste(5) < waste(7) - 0.03 ? 5 : 7;
+}
+
+int launch_flatd(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh, float *out,
+                 hipStream_t s)
+{
+    const int var = flatd_variant(sh, x, w);
+    if (var == 0) return QE_ERR_UNSUPPORTED;
+    FlatdArgs a;
+    a.x = static_cast<const uint8_t *>(x->data); a.w = static_cast<const uint8_t *>(w->data);
+    a.x_scale = x->scale; a.x_zero = x->zero; a.w_scale = w->scale; a.w_zero = w->zero; a.bias = bias;
+    a.x_sign = x->sign; a.w_sign = w->sign; a.w_per_tensor = (w->n_param == 1);
+    a.out = out; a.N = sh->N; a.IC = sh->IC; a.OC = sh->OC; a.P = sh->H * sh->W;
+    a.n_oc_tiles = (sh->OC + FD_MT - 1) / FD_MT;
+    if (var == 8) { a.tiles_per_image = 1; a.n_pix_tiles = (sh->N + 3) / 4; }
+    else { a.tiles_per_image = (a.P + 32 * var - 1) / (32 * var); a.n_pix_tiles = sh->N * a.tiles_per_image; }
+    a.dbg = getenv("QE_FLATD_DBG") ? atoi(getenv("QE_FLATD_DBG")) : 0;
+    const int64_t per_xcd = ((int64_t)a.n_pix_tiles + 7) / 8;
+    a.chunk = (int)(per_xcd < 1 ? 1 : per_xcd);
+    if (const char *ci = getenv("QE_CHUNK_IMAGES")) {
+        const int64_t k = (int64_t)atoi(ci) * a.tiles_per_image;
+        a.chunk = (int)(k < 1 ? 1 : (k < per_xcd ? k : per_xcd));
+    }
+    const int64_t runs = ((int64_t)a.n_pix_tiles + a.chunk - 1) / a.chunk;
+    const int64_t blocks = (runs + 7) / 8 * a.chunk * 8 * a.n_oc_tiles;
+    if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
+    static const bool raised = [] {
+        bool ok = true;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_flatd_kernel<5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, FdGeom<5, false>::LDS) == hipSuccess;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_flatd_kernel<7, false>), hipFuncAttributeMaxDynamicSharedMemorySize, FdGeom<7, false>::LDS) == hipSuccess;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_flatd_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FdGeom<8, true>::LDS) == hipSuccess;
+        return ok;
+    }();
+    (void)raised;
+    constexpr size_t lds8 = FdGeom<8, true>::LDS, lds5 = FdGeom<5, false>::LDS, lds7 = FdGeom<7, false>::LDS;
+    if (var == 8) hipLaunchKernelGGL((conv_flatd_kernel<8, true>), dim3((unsigned)blocks), dim3(256), lds8, s, a);
+    else if (var == 5) hipLaunchKernelGGL((conv_flatd_kernel<5, false>), dim3((unsigned)blocks), dim3(256), lds5, s, a);
+    else hipLaunchKernelGGL((conv_flatd_kernel<7, false>), dim3((unsigned)blocks), dim3(256), lds7, s, a);
+    QE_LAUNCH_CHECK();
+    return QE_OK;
+}
+
+}  // namespace qe

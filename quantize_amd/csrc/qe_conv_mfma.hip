@@ -549,6 +549,9 @@ __global__ __launch_bounds__(256) void subsample_kernel(const uint8_t *__restric
 unsigned long long *g_mfma_dbg = nullptr;   // also read by qe_linear.hip (diagnostic builds)
 
 int expand_codes_s8(const uint8_t *packed, int64_t n, int n_bits, int sign, uint8_t *out, hipStream_t s);   // qe_tpack.hip
+int flatd_variant(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w);                          // qe_conv_flatd.hip
+int launch_flatd(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh, float *out, hipStream_t s);
+constexpr int QE_FLATD_DEFAULT = 4;   // 7x7 planes only: -17..-20 % there; the wide variants tie or lose to the register-staged kernels (profiles/r02b_ab_flatd.txt)
 
 bool mfma_conv_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w)
 {
@@ -605,6 +608,17 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
         xs.data = wsp + p.sub_off;
         x = &xs;
         sh = &shd;
+    }
+
+    // 1x1 / stride 1 layers with 8-bit operands and IC % 64 == 0: the LDS-DMA ring kernel (qe_conv_flatd.hip).
+    // QE_FLATD=0 keeps the register-staged flat kernels; QE_FLATD=<bitmask> enables it per tile variant
+    // (1: 224-pixel tiles, 2: 160-pixel tiles, 4: 7x7 planes); default from the per-layer A/B in DESIGN.md.
+    {
+        const int var = flatd_variant(sh, x, w);
+        const char *e = getenv("QE_FLATD");
+        const int mask = e ? atoi(e) : QE_FLATD_DEFAULT;
+        const int bit = var == 7 ? 1 : (var == 5 ? 2 : (var == 8 ? 4 : 0));
+        if (var != 0 && (mask & bit)) return launch_flatd(x, w, bias, sh, out, s);
     }
 
     PrepArgs pa;
