@@ -87,6 +87,22 @@ int qe_tunpack(const uint8_t *packed, int64_t n, int n_bits, int sign,
                void *out, qe_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * qe_quantize_pack -- Quantizer + tpack in one pass
+ *   reference: modelzoo/modules/quantizer.py:31,213-226 (q = round(x / scale - zero).clamp(qmin, qmax), returned as an
+ *   integer-valued fp32 tensor in packed mode) followed by engine.tpack (tpack.cu:203-255).
+ * The packed conv / linear operators have no producer for their activation operand in the reference (the module
+ * hands fp32 q to F.conv2d); this is that producer: fp32 activations in, the b-bit stream qe_quantconv2d takes out,
+ * without the 4 B/element intermediate.  out is bit-identical to qe_tpack(round(x / scale - zero).clamp(..)).
+ * scale/zero  n_param fp32 elements in the MODULE's convention (the value is x / scale - zero; the conv kernels'
+ *             (q - zero') dequantisation takes zero' = -zero).  n_param == 1: per tensor; otherwise per channel with
+ *             channel(i) = (i / inner) % n_param  (NCHW activations: inner = H*W, n_param = C).
+ * status      as qe_tpack: bit 0 set when a clamped value does not fit n_bits/sign (or is NaN).
+ * ------------------------------------------------------------------------- */
+int qe_quantize_pack(const float *x, int64_t n, const float *scale, const float *zero, int32_t n_param,
+                     int64_t inner, float qmin, float qmax, int n_bits, int sign, uint8_t *out,
+                     int32_t *status, qe_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Convolution problem description shared by the two conv entry points.
  * Shapes follow the reference's host code: square stride/padding, no dilation,
  * no groups (functions/quantconv2d.cu:198-211).  OH/OW are derived:
@@ -133,6 +149,27 @@ size_t qe_quantconv2d_workspace_bytes(const qe_conv_shape *shape, int x_bits, in
 int qe_quantconv2d(const qe_qparam *x, const qe_qparam *w, const float *bias,
                    const qe_conv_shape *shape, float *out,
                    void *workspace, size_t workspace_bytes, qe_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Weights kept prepared across calls.
+ *   reference: modelzoo/modules/quantconv2d.py:187-192 (pack() stores the packed weight once) and :230-233 (the
+ *   TODO "remove tunpack in loading state_dict, and add support for custom operators"): a packed layer's weights,
+ *   scales and bias never change between forward passes, yet the reference op receives them packed on every call.
+ * qe_conv_prepare runs the x-independent part of qe_quantconv2d once -- the packed OIHW stream re-laid out as
+ * int8 MFMA fragments, per-channel (sw, zw', bias) and the border-aware tap-sum tables -- into a caller-owned
+ * device buffer of qe_conv_prepared_bytes() bytes; qe_quantconv2d_prepared then runs only the convolution.
+ * Results are bit-identical to qe_quantconv2d.  x_bits selects the kernel plan the tables are laid out for and
+ * must match the activations passed later; w / bias must be the same tensors (the 1x1 kernels still read them).
+ * qe_conv_prepared_bytes() == 0: nothing to prepare (the kernel consumes the packed weights directly); both
+ * calls then accept prepared == NULL.  Scratch for the prepared call: qe_quantconv2d_prepared_workspace_bytes().
+ * ------------------------------------------------------------------------- */
+size_t qe_conv_prepared_bytes(const qe_conv_shape *shape, int x_bits, int w_bits);
+size_t qe_quantconv2d_prepared_workspace_bytes(const qe_conv_shape *shape, int x_bits, int w_bits);
+int qe_conv_prepare(const qe_qparam *w, const float *bias, const qe_conv_shape *shape, int x_bits,
+                    void *prepared, size_t prepared_bytes, qe_stream_t stream);
+int qe_quantconv2d_prepared(const qe_qparam *x, const qe_qparam *w, const float *bias,
+                            const qe_conv_shape *shape, const void *prepared, size_t prepared_bytes,
+                            float *out, void *workspace, size_t workspace_bytes, qe_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * qe_quantconv2d_float_input -- replaces quantconv2d_float_input()/..._cuda

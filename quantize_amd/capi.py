@@ -19,7 +19,8 @@ DTYPES = {"uint8": 0, "int8": 1, "int16": 2, "int32": 3, "int64": 4,
 SYMBOLS = ["qe_error_string", "qe_last_hip_error", "qe_version", "qe_target_arch", "qe_packed_nbytes",
            "qe_tpack", "qe_tunpack", "qe_quantconv2d_workspace_bytes", "qe_quantconv2d",
            "qe_quantconv2d_float_input", "qe_quantconv2d_path", "qe_quantlinear", "qe_quantlinear_float_input",
-           "qe_quantlinear_path", "qe_global_avgpool"]
+           "qe_quantlinear_path", "qe_global_avgpool", "qe_conv_prepared_bytes", "qe_quantconv2d_prepared_workspace_bytes",
+           "qe_conv_prepare", "qe_quantconv2d_prepared", "qe_quantize_pack"]
 
 
 class QeConvShape(ctypes.Structure):
@@ -73,6 +74,17 @@ def lib():
     L.qe_quantlinear_path.argtypes = [ctypes.POINTER(QeQParam), ctypes.POINTER(QeQParam), i64, i32, i32]
     L.qe_global_avgpool.restype = i32
     L.qe_global_avgpool.argtypes = [vp, i64, i32, vp, vp]
+    L.qe_conv_prepared_bytes.restype = sz
+    L.qe_conv_prepared_bytes.argtypes = [ctypes.POINTER(QeConvShape), i32, i32]
+    L.qe_quantconv2d_prepared_workspace_bytes.restype = sz
+    L.qe_quantconv2d_prepared_workspace_bytes.argtypes = [ctypes.POINTER(QeConvShape), i32, i32]
+    L.qe_conv_prepare.restype = i32
+    L.qe_conv_prepare.argtypes = [ctypes.POINTER(QeQParam), vp, ctypes.POINTER(QeConvShape), i32, vp, sz, vp]
+    L.qe_quantconv2d_prepared.restype = i32
+    L.qe_quantconv2d_prepared.argtypes = [ctypes.POINTER(QeQParam), ctypes.POINTER(QeQParam), vp, ctypes.POINTER(QeConvShape),
+                                          vp, sz, vp, vp, sz, vp]
+    L.qe_quantize_pack.restype = i32
+    L.qe_quantize_pack.argtypes = [vp, i64, vp, vp, i32, i64, ctypes.c_float, ctypes.c_float, i32, i32, vp, vp, vp]
     _lib = L
     return L
 
@@ -159,6 +171,49 @@ def quantconv2d(xq, wq, bias, sh, out=None, workspace=None, stream=None):
                                None if workspace is None else workspace.data_ptr(),
                                0 if workspace is None else workspace.numel(), _stream(stream)))
     return out
+
+
+def conv_prepare(wq, bias, sh, x_bits, stream=None):
+    """qe_conv_prepare: the x-independent tables of a conv layer, once.  Returns a uint8 device tensor (possibly empty)."""
+    import torch
+    dev = wq._keep[0].device
+    need = int(lib().qe_conv_prepared_bytes(ctypes.byref(sh), int(x_bits), wq.n_bits))
+    prepared = torch.empty(max(need, 0), dtype=torch.uint8, device=dev)
+    check(lib().qe_conv_prepare(ctypes.byref(wq), None if bias is None else bias.data_ptr(), ctypes.byref(sh), int(x_bits),
+                                prepared.data_ptr() if need else None, need, _stream(stream)))
+    return prepared
+
+
+def quantconv2d_prepared(xq, wq, bias, sh, prepared, out=None, workspace=None, stream=None):
+    import torch
+    dev = wq._keep[0].device
+    OH, OW = out_hw(sh)
+    if out is None:
+        out = torch.empty((sh.N, sh.OC, OH, OW), dtype=torch.float32, device=dev)
+    need = int(lib().qe_quantconv2d_prepared_workspace_bytes(ctypes.byref(sh), xq.n_bits, wq.n_bits))
+    if workspace is None and need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    check(lib().qe_quantconv2d_prepared(ctypes.byref(xq), ctypes.byref(wq), None if bias is None else bias.data_ptr(),
+                                        ctypes.byref(sh), prepared.data_ptr() if prepared.numel() else None, prepared.numel(),
+                                        out.data_ptr(), None if workspace is None else workspace.data_ptr(),
+                                        0 if workspace is None else workspace.numel(), _stream(stream)))
+    return out
+
+
+def quantize_pack(x, scale, zero, qmin, qmax, n_bits, sign, inner=1, out=None, status=None, stream=None):
+    """qe_quantize_pack: round(x / scale - zero).clamp(qmin, qmax) packed to n_bits; per channel when scale has > 1
+    element (channel(i) = (i / inner) % numel(scale))."""
+    import torch
+    assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and scale.numel() == zero.numel()
+    n = x.numel()
+    if out is None:
+        out = torch.empty(packed_nbytes(n, n_bits), dtype=torch.uint8, device=x.device)
+    if status is None:
+        status = torch.zeros(1, dtype=torch.int32, device=x.device)
+    check(lib().qe_quantize_pack(x.data_ptr(), n, scale.data_ptr(), zero.data_ptr(), int(scale.numel()), int(inner),
+                                 float(qmin), float(qmax), int(n_bits), 1 if sign else 0, out.data_ptr(), status.data_ptr(),
+                                 _stream(stream)))
+    return out, status
 
 
 def quantconv2d_float_input(x, wq, bias, sh, out=None, stream=None):

@@ -12,8 +12,10 @@ int launch_conv_generic(bool packed_in, const void *x, const qe_qparam *xq, cons
 // qe_conv_mfma.hip
 bool mfma_conv_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w);
 size_t mfma_conv_workspace_bytes(const qe_conv_shape *sh, int x_bits, int w_bits);
+size_t mfma_conv_prepared_bytes(const qe_conv_shape *sh, int x_bits, int w_bits);
 int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh,
-                     float *out, void *workspace, size_t workspace_bytes, hipStream_t s);
+                     float *out, void *workspace, size_t workspace_bytes, hipStream_t s, int mode, void *prepared,
+                     size_t prepared_bytes);
 
 static int check_shape(const qe_conv_shape *sh)
 {
@@ -77,8 +79,50 @@ extern "C" int qe_quantconv2d(const qe_qparam *x, const qe_qparam *w, const floa
     if (out == nullptr) return QE_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (mfma_conv_eligible(shape, x, w))
-        return launch_conv_mfma(x, w, bias, shape, out, workspace, workspace_bytes, s);
+        return launch_conv_mfma(x, w, bias, shape, out, workspace, workspace_bytes, s, 0, nullptr, 0);
     return launch_conv_generic(true, x->data, x, w, bias, shape, out, s);
+}
+
+extern "C" size_t qe_conv_prepared_bytes(const qe_conv_shape *shape, int x_bits, int w_bits)
+{
+    if (qe::check_shape(shape) != QE_OK) return 0;
+    return qe::mfma_conv_prepared_bytes(shape, x_bits, w_bits);
+}
+
+extern "C" size_t qe_quantconv2d_prepared_workspace_bytes(const qe_conv_shape *shape, int x_bits, int w_bits)
+{
+    if (qe::check_shape(shape) != QE_OK) return 0;
+    return qe::mfma_conv_workspace_bytes(shape, x_bits, w_bits) - qe::mfma_conv_prepared_bytes(shape, x_bits, w_bits);
+}
+
+extern "C" int qe_conv_prepare(const qe_qparam *w, const float *bias, const qe_conv_shape *shape, int x_bits,
+                               void *prepared, size_t prepared_bytes, qe_stream_t stream)
+{
+    using namespace qe;
+    int rc = check_shape(shape);
+    if (rc != QE_OK) return rc;
+    if ((rc = check_qparam(w)) != QE_OK) return rc;
+    if (!(x_bits > 0 && x_bits <= 8)) return QE_ERR_NBITS;
+    if (mfma_conv_prepared_bytes(shape, x_bits, w->n_bits) == 0) return QE_OK;     // nothing to prepare for this problem
+    qe_qparam x = *w;                      // only n_bits / n_param of the activations select the plan
+    x.n_bits = x_bits; x.n_param = 1;
+    return launch_conv_mfma(&x, w, bias, shape, nullptr, nullptr, 0, static_cast<hipStream_t>(stream), 1, prepared, prepared_bytes);
+}
+
+extern "C" int qe_quantconv2d_prepared(const qe_qparam *x, const qe_qparam *w, const float *bias,
+                                       const qe_conv_shape *shape, const void *prepared, size_t prepared_bytes,
+                                       float *out, void *workspace, size_t workspace_bytes, qe_stream_t stream)
+{
+    using namespace qe;
+    int rc = check_shape(shape);
+    if (rc != QE_OK) return rc;
+    if ((rc = check_qparam(x)) != QE_OK) return rc;
+    if ((rc = check_qparam(w)) != QE_OK) return rc;
+    if (out == nullptr) return QE_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (mfma_conv_eligible(shape, x, w))
+        return launch_conv_mfma(x, w, bias, shape, out, workspace, workspace_bytes, s, 2, const_cast<void *>(prepared), prepared_bytes);
+    return launch_conv_generic(true, x->data, x, w, bias, shape, out, s);   // per-channel activation scales: nothing is prepared
 }
 
 extern "C" int qe_quantconv2d_float_input(const float *x, const qe_qparam *w, const float *bias,

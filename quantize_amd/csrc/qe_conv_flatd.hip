@@ -32,8 +32,6 @@
 
 namespace qe {
 
-extern unsigned long long *g_mfma_dbg;   // qe_conv_mfma.hip: stamp buffer of -DQE_STAMP diagnostic builds
-
 struct FlatdArgs {
     const uint8_t *x;          // [N][IC][P] stored codes, 8-bit
     const uint8_t *w;          // [OC][IC] stored codes, 8-bit
@@ -43,8 +41,6 @@ struct FlatdArgs {
     int N, IC, OC, P;
     int tiles_per_image;       // WIDE: pixel tiles per plane; SMALL: unused
     int n_pix_tiles, n_oc_tiles, chunk;
-    unsigned long long *stamp; // -DQE_STAMP diagnostic builds: per-wave phase cycle sums (tools/stamp_layer.py)
-    int dbg;                   // tuning experiments (QE_FLATD_DBG): 1 = no output stores, 2 = no K loop (stores only), 4 = no MFMA phase
 };
 
 constexpr int FD_CK = 64;              // channels per stage
@@ -248,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv_flatd_kernel(const FlatdArgs a)
         pw[i] = a.w + (int64_t)orow * a.IC + 16 * (sl ^ ((r >> 2) & 3));
     }
     const int64_t x_step = (int64_t)FD_CK * P;
-    const int n_stages = (a.dbg & 2) ? 0 : a.IC / FD_CK;
+    const int n_stages = a.IC / FD_CK;
     auto issue = [&](int s) __attribute__((always_inline)) {
         uint8_t *buf = smem + (s % FD_RING) * G::STAGE;
         // the one slot that would read past the tensor (last stage of the last plane) is left out of the DMA: its lane is
@@ -257,18 +253,17 @@ __global__ __launch_bounds__(256, 2) void conv_flatd_kernel(const FlatdArgs a)
         const int skip = (s == n_stages - 1) ? fix_i : -1;
 #pragma unroll
         for (int i = 0; i < PXW; ++i) {
-            if (i < n_xi && i != skip && !(a.dbg & 16))    // first term wave-uniform, second per lane (EXEC mask)
+            if (i < n_xi && i != skip)    // first term wave-uniform, second per lane (EXEC mask)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(px[i] + s * x_step),
                                                  (__attribute__((address_space(3))) void *)(buf + 1024 * (wave + 4 * i)), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            if (!(a.dbg & 8))
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pw[i] + s * FD_CK),
                                              (__attribute__((address_space(3))) void *)(buf + G::XBYTES + (256 * i + 64 * wave) * 16), 16, 0, 0);
     };
 
-    if (n_stages > 0) issue(0);
+    issue(0);
     if (n_stages > 1) issue(1);
 
     // S_x (per-pixel channel sums) is only needed by output channels with zw' != 0: decided per WAVE (its 32 channels),
@@ -307,16 +302,7 @@ __global__ __launch_bounds__(256, 2) void conv_flatd_kernel(const FlatdArgs a)
         constexpr bool SX = decltype(sx_tag)::value;
         for (int s = 0; s < n_stages; ++s) {
             // stage s has landed for this wave once at most the pieces of stage s + 1 are still outstanding
-            if ((a.dbg & 24) && s + 1 < n_stages) {
-                const int n = ((a.dbg & 16) ? 0 : n_xi) + ((a.dbg & 8) ? 0 : 2);   // experiments: pieces of one stage
-                switch (n) {
-                    case 0: __builtin_amdgcn_s_waitcnt(0x0f70); break;
-                    case 2: __builtin_amdgcn_s_waitcnt(0x0f72); break;
-                    case 3: __builtin_amdgcn_s_waitcnt(0x0f73); break;
-                    case 4: __builtin_amdgcn_s_waitcnt(0x0f74); break;
-                    default: __builtin_amdgcn_s_waitcnt(0x0f70); break;
-                }
-            } else if (s + 1 < n_stages) {
+                if (s + 1 < n_stages) {
                 if (n_xi == PXW) __builtin_amdgcn_s_waitcnt(0x0f70 | (PXW + 2)); else __builtin_amdgcn_s_waitcnt(0x0f70 | (PXW + 1));
             } else {
                 __builtin_amdgcn_s_waitcnt(0x0f70);
@@ -328,7 +314,6 @@ __global__ __launch_bounds__(256, 2) void conv_flatd_kernel(const FlatdArgs a)
             }
             __builtin_amdgcn_s_barrier();             // ... for every wave; and ring slot (s + 2) % 3 has no reader left
             if (s + 2 < n_stages) issue(s + 2);
-            if (a.dbg & 4) continue;                  // experiment: DMA ring only, no fragment reads / MFMA
             // per 32-channel chunk: one asm statement = weight fragment + every activation fragment + their wait
             const uint32_t xb = smem_lds + (uint32_t)((s % FD_RING) * G::STAGE);
 #pragma unroll
@@ -372,7 +357,6 @@ __global__ __launch_bounds__(256, 2) void conv_flatd_kernel(const FlatdArgs a)
         }
     }
     __syncthreads();          // every wave is done with the ring (it becomes the store patches)
-    if (a.dbg & 1) return;
     if constexpr (!SMALL) {
         // each wave turns its 32 oc x 32 px tiles through a private patch: one global_store_dwordx4 = 8 rows x 128 B
         const int NTv = min(G::NTP, P - p0);
@@ -447,296 +431,6 @@ __global__ __launch_bounds__(256, 2) void conv_flatd_kernel(const FlatdArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Persistent form of the WIDE variant ("flatp").  Measured on the one-tile-per-workgroup kernel above (profiles/r02c_*):
-// a layer's time is the SUM of its load phase and its store phase (every workgroup loads, then stores, and all of them
-// start together), the load phase itself is latency bound (about 3 us per HBM round trip under load: a workgroup with a
-// 4-stage K loop and 2 stages in flight spends two round trips before its first store), and the stores alone run at the
-// rate a store-only kernel reaches.  So a workgroup here keeps ONE output-channel tile and walks a run of pixel tiles;
-// the DMA ring (32-channel stages, 5 slots, 4 stages in flight) never drains between tiles: while a tile's epilogue
-// stores go out, the next tile's stages are already landing.  The epilogue gets its own LDS patches.
-// vmcnt bookkeeping: loads, LDS-DMA and stores retire in issue order, so "stage g has landed" = at most the operations
-// issued after its DMA are outstanding: the (AHEAD-1) younger stages, plus -- for the AHEAD iterations that follow an
-// epilogue -- that epilogue's stores, whose exact number each wave knows (every store instruction sits under a
-// wave-uniform condition).
-// ---------------------------------------------------------------------------------------------
-constexpr int FP_CK = 32, FP_RING = 5, FP_AHEAD = 4;
-
-template <int NT> struct FpGeom {
-    static constexpr int RS = 32 * NT;
-    static constexpr int XBYTES = FP_CK * RS;
-    static constexpr int WBYTES = FD_MT * FP_CK;
-    static constexpr int STAGE = XBYTES + WBYTES;
-    static constexpr int XINSTR = XBYTES / 1024;
-    static constexpr int NTP = 32 * NT;
-    static constexpr int PATCH_OFF = FP_RING * STAGE;
-    static constexpr int SX_OFF = PATCH_OFF + 4 * 32 * 36 * 4;
-    static constexpr int LDS = SX_OFF + 4 * NTP * 4;
-};
-
-__device__ __forceinline__ void wait_vmcnt_dyn(int n)   // n wave-uniform, 0..63
-{
-#define QE_VMW(k) case k: __builtin_amdgcn_s_waitcnt(0x0f70 | ((k) & 15) | (((k) >> 4) << 14)); break;
-    switch (n) {
-        QE_VMW(0) QE_VMW(1) QE_VMW(2) QE_VMW(3) QE_VMW(4) QE_VMW(5) QE_VMW(6) QE_VMW(7) QE_VMW(8) QE_VMW(9)
-        QE_VMW(10) QE_VMW(11) QE_VMW(12) QE_VMW(13) QE_VMW(14) QE_VMW(15) QE_VMW(16) QE_VMW(17) QE_VMW(18) QE_VMW(19)
-        QE_VMW(20) QE_VMW(21) QE_VMW(22) QE_VMW(23) QE_VMW(24) QE_VMW(25) QE_VMW(26) QE_VMW(27) QE_VMW(28) QE_VMW(29)
-        QE_VMW(30) QE_VMW(31) QE_VMW(32) QE_VMW(33) QE_VMW(34) QE_VMW(35) QE_VMW(36) QE_VMW(37) QE_VMW(38) QE_VMW(39)
-        QE_VMW(40) QE_VMW(41) QE_VMW(42) QE_VMW(43) QE_VMW(44) QE_VMW(45) QE_VMW(46) QE_VMW(47) QE_VMW(48)
-        default: __builtin_amdgcn_s_waitcnt(0x0f70); break;
-    }
-#undef QE_VMW
-}
-
-template <int NT>
-__global__ __launch_bounds__(256, 2) void conv_flatp_kernel(const FlatdArgs a)
-{
-    using G = FpGeom<NT>;
-    constexpr int RS = G::RS, SPR = RS / 16;
-    static_assert((NT & 1) == 1, "row stride must be an odd multiple of 32 B");
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int col = lane & 31, h = lane >> 5;
-    const int P = a.P;
-
-    // workgroup -> (output-channel tile, run of pixel tiles).  Blocks b and b + 8 share an XCD: the oc tiles of one run
-    // get consecutive idx (same XCD, started together: they stream the same activations through one L2), and XCD x
-    // owns the runs x, x + 8, ... -- each run a contiguous range of pixel tiles.
-    const int idx = blockIdx.x >> 3;
-    const int ot = idx % a.n_oc_tiles;
-    const int run = (idx / a.n_oc_tiles) * 8 + (blockIdx.x & 7);
-    const int t_lo = run * a.chunk;                    // a.chunk = pixel tiles per run
-    const int n_tiles = min(a.chunk, a.n_pix_tiles - t_lo);
-    if (n_tiles <= 0) return;
-
-    // ---- constants of this lane's output channel (fixed for the workgroup's life) -------------------------------
-    const int oc = ot * FD_MT + wave * 32 + col;
-    const int occ = oc < a.OC ? oc : a.OC - 1;
-    const float sw = a.w_per_tensor ? a.w_scale[0] : a.w_scale[occ];
-    const float zwp = (a.w_per_tensor ? a.w_zero[0] : a.w_zero[occ]) - (a.w_sign ? 0.0f : 128.0f);
-    float alpha = a.x_scale[0] * sw;
-    float bia = a.bias ? a.bias[occ] : 0.0f;
-    const float zxp = a.x_zero[0] - (a.x_sign ? 0.0f : 128.0f);
-    const bool need_sx = __builtin_amdgcn_ballot_w64(oc < a.OC && zwp != 0.0f) != 0ull;
-    uint32_t fix_val = 0;                               // the tensor's last 4 bytes (planes with P % 16 == 4)
-    if ((P & 15) != 0) __builtin_memcpy(&fix_val, a.x + (int64_t)a.N * a.IC * P - 4, 4);
-    __builtin_amdgcn_s_waitcnt(0x0f70);                 // every ordinary load has returned before the first DMA is counted
-    asm volatile("" : "+v"(alpha), "+v"(bia), "+v"(fix_val));
-
-    // ---- DMA addressing -----------------------------------------------------------------------------------------
-    constexpr int PXW = (G::XINSTR + 3) / 4;
-    const int n_xi = (G::XINSTR % 4 == 0 || wave < G::XINSTR % 4) ? PXW : PXW - 1;
-    const int pcs = n_xi + 1;                           // DMA instructions per stage of this wave (X + one W)
-    int xrel[PXW], xc[PXW], xj[PXW];
-#pragma unroll
-    for (int i = 0; i < PXW; ++i) {
-        const int e = 64 * (wave + 4 * i) + lane;
-        xc[i] = e / SPR;
-        xj[i] = e - xc[i] * SPR;
-        xrel[i] = xc[i] * P + 16 * xj[i];
-    }
-    const uint8_t *pwp;
-    {
-        const int r = tid >> 1, sl = tid & 1;           // weight slot tid: row r of the tile, position sl holds k-piece sl ^ ((r >> 3) & 1)
-        const int orow = ot * FD_MT + r < a.OC ? ot * FD_MT + r : a.OC - 1;
-        pwp = a.w + (int64_t)orow * a.IC + 16 * (sl ^ ((r >> 3) & 1));
-    }
-    const int n_stages = a.IC / FP_CK;
-    const int total = n_tiles * n_stages;
-    const int64_t x_last16 = (int64_t)a.N * a.IC * P - 16;
-    const int64_t x_step = (int64_t)FP_CK * P;
-
-    // issue side state: tile ik, stage is of the next stage to request
-    int ik = 0, is = 0;
-    const uint8_t *xt = nullptr;                        // a.x + first byte of the issue tile's first channel
-    int xflag[PXW];                                     // 0: plain, 1: last stage of the tensor's last plane reads the last 16 bytes instead
-                                                        // (pure garbage slot), 2: ... is left out (partly valid: written by this lane)
-    auto tile_geom = [&](int k, int &n0, int &p0) __attribute__((always_inline)) {
-        const int pt = t_lo + k;
-        n0 = pt / a.tiles_per_image;
-        p0 = (pt - n0 * a.tiles_per_image) * G::NTP;
-    };
-    auto issue_next = [&](int g) __attribute__((always_inline)) {
-        if (is == 0) {
-            int n0, p0;
-            tile_geom(ik, n0, p0);
-            xt = a.x + (int64_t)n0 * a.IC * P + p0;
-#pragma unroll
-            for (int i = 0; i < PXW; ++i) {
-                const int pos = p0 + 16 * xj[i];
-                const bool lastrow = (n0 == a.N - 1) && xc[i] == FP_CK - 1 && pos + 16 > P;
-                xflag[i] = !lastrow ? 0 : (pos < P ? 2 : 1);
-            }
-        }
-        uint8_t *buf = smem + (g % FP_RING) * G::STAGE;
-        const bool last = is == n_stages - 1;
-#pragma unroll
-        for (int i = 0; i < PXW; ++i) {
-            if (i < n_xi) {
-                const uint8_t *src = xt + xrel[i] + is * x_step;
-                if (last && xflag[i] == 1) src = a.x + x_last16;
-                if (!(last && xflag[i] == 2))
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                     (__attribute__((address_space(3))) void *)(buf + 1024 * (wave + 4 * i)), 16, 0, 0);
-            }
-        }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pwp + is * FP_CK),
-                                         (__attribute__((address_space(3))) void *)(buf + G::XBYTES + 1024 * wave), 16, 0, 0);
-        if (++is == n_stages) { is = 0; ++ik; }
-    };
-
-    v16i acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0;
-    int swacc = 0;
-    int sxacc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) sxacc[t] = 0;
-
-    const int i16 = lane & 15;
-    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
-    const uint32_t tr_b = (uint32_t)((16 * h + (i16 >> 1)) * RS + 16 * ((lane >> 4) & 1) + 8 * (i16 & 1));
-    const uint32_t wf_b = (uint32_t)(G::XBYTES + (wave * 32 + col) * FP_CK + 16 * (h ^ ((col >> 3) & 1)));
-    const uint32_t patch_lds = smem_lds + (uint32_t)(G::PATCH_OFF + wave * (32 * 36 * 4));
-    int *sxp = reinterpret_cast<int *>(smem + G::SX_OFF) + wave * G::NTP;
-    const int rrow = lane >> 3, rq = lane & 7;
-    const int oc_w0 = ot * FD_MT + wave * 32;
-    int n_i = 0;                                        // 8-row store groups of this wave that hold a real channel
-#pragma unroll
-    for (int i = 0; i < 4; ++i) n_i += (oc_w0 + 8 * i < a.OC) ? 1 : 0;
-
-#ifdef QE_STAMP
-    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tprev = qe_stamp();
-    const unsigned long long tstart = tprev;
-#endif
-    for (int g = 0; g < FP_AHEAD && g < total; ++g) issue_next(g);
-    QE_ST(0);   // prologue: first AHEAD stages requested
-
-    int ck = 0, cs = 0;                                 // compute side: tile, stage
-    int sp = 0, n_st = 0;                               // iterations that still see the last epilogue's n_st stores in the queue
-    bool sw_done = false;
-    for (int g = 0; g < total; ++g) {
-        const int rem = min(FP_AHEAD - 1, total - 1 - g);
-        wait_vmcnt_dyn(rem * pcs + (sp > 0 ? n_st : 0));
-        QE_ST(1);   // wait for the stage's DMA (and whatever is older in the queue)
-        if (sp > 0) --sp;
-        if (cs == n_stages - 1 && (P & 15) != 0) {
-            // the partly valid slot of the tensor's last plane was left out of the DMA: its lane stores the 4 valid bytes
-            int n0, p0;
-            tile_geom(ck, n0, p0);
-            if (n0 == a.N - 1) {
-#pragma unroll
-                for (int i = 0; i < PXW; ++i) {
-                    const int pos = p0 + 16 * xj[i];
-                    if (i < n_xi && xc[i] == FP_CK - 1 && pos < P && pos + 16 > P)
-                        *reinterpret_cast<uint32_t *>(smem + (g % FP_RING) * G::STAGE + 16 * (64 * (wave + 4 * i) + lane)) = fix_val;
-                }
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-            }
-        }
-        __builtin_amdgcn_s_barrier();
-        QE_ST(2);   // barrier
-        if (g + FP_AHEAD < total) issue_next(g + FP_AHEAD);
-        QE_ST(3);   // DMA issue
-        if (!(a.dbg & 4)) {
-            const uint32_t xb = smem_lds + (uint32_t)((g % FP_RING) * G::STAGE);
-            v2i lo[NT], hi[NT];
-            v4i wf;
-            fd_reads_wide<NT>(xb + tr_b, xb + wf_b, wf, lo, hi);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                wf[j] ^= (int)0x80808080;
-                if (!sw_done) swacc = __builtin_amdgcn_sdot4(wf[j], 0x01010101, swacc, false);   // S_w: first tile only (same weights every tile)
-            }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                v4i xf = {lo[t][0], lo[t][1], hi[t][0], hi[t][1]};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) xf[j] ^= (int)0x80808080;
-                if (need_sx) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) sxacc[t] = __builtin_amdgcn_sdot4(xf[j], 0x01010101, sxacc[t], false);
-                }
-                acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xf, wf, acc[t], 0, 0, 0);
-            }
-        }
-        QE_ST(4);   // fragment reads + MFMA
-        if (++cs < n_stages) continue;
-
-        // ---- epilogue of tile ck (every wave on its own: private patch, no workgroup barrier) ----------------------
-        cs = 0;
-        sw_done = true;
-        int n0, p0;
-        tile_geom(ck, n0, p0);
-        ++ck;
-        const int sw_sum = swacc + __shfl_xor(swacc, 32);
-        const float cst = fmaf((float)a.IC * zxp, zwp, -zxp * (float)sw_sum);
-        if (need_sx) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int v = sxacc[t] + __shfl_xor(sxacc[t], 32);
-                if (h == 0) sxp[32 * t + col] = v;
-                sxacc[t] = 0;
-            }
-        }
-        const int NTv = min(G::NTP, P - p0);
-        float *out_w = a.out + ((int64_t)n0 * a.OC + oc_w0) * P + p0;
-        const uint32_t voff = (uint32_t)rrow * (uint32_t)P + 4u * (uint32_t)rq;
-        int stores = 0;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int q0 = t * 32;
-            if (q0 < NTv && n_i > 0 && !(a.dbg & 1)) {          // wave-uniform
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    float v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float f = (float)acc[t][4 * gq + j] + cst;
-                        if (need_sx) f = fmaf(-zwp, (float)sxp[q0 + 8 * gq + 4 * h + j], f);
-                        v[j] = fmaf(alpha, f, bia);
-                    }
-                        // patch accesses in asm: a plain LDS store here makes hipcc drain every DMA in flight first (vmcnt(0))
-                    fd_patch_write(patch_lds + 4u * (uint32_t)(col * 36 + 8 * gq + 4 * h), v[0], v[1], v[2], v[3]);
-                }
-                fd_lds_drain();
-                const bool px_ok = q0 + 4 * rq < NTv;
-                v4i o[4];
-                fd_patch_read4(patch_lds + 4u * (uint32_t)(rrow * 36 + 4 * rq), o[0], o[1], o[2], o[3]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (i < n_i) {                                  // wave-uniform: exactly one store instruction each
-                        const int row = 8 * i + rrow;
-                        const float4 o4 = make_float4(__int_as_float(o[i][0]), __int_as_float(o[i][1]), __int_as_float(o[i][2]), __int_as_float(o[i][3]));
-                        if (px_ok && oc_w0 + row < a.OC)
-                            *reinterpret_cast<float4 *>(out_w + (int64_t)(8 * i) * P + q0 + voff) = o4;
-                    }
-                }
-                stores += n_i;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0;
-        }
-        n_st = stores;
-        sp = FP_AHEAD;
-        QE_ST(5);   // epilogue: conversions, patch round trips, stores issued
-    }
-#ifdef QE_STAMP
-    __builtin_amdgcn_s_waitcnt(0x0f70);
-    QE_ST(6);       // final store drain
-    if (a.stamp != nullptr && lane == 0) {
-        unsigned long long *o = a.stamp + ((size_t)blockIdx.x * 4 + wave) * 10;
-        for (int i = 0; i < 8; ++i) o[i] = st[i];
-        o[8] = tprev - tstart;
-        o[9] = tstart;
-    }
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 // tile variant: 0 = none, 5 / 7 = WIDE with that many column tiles, 8 = SMALL
@@ -768,31 +462,6 @@ int launch_flatd(const qe_qparam *x, const qe_qparam *w, const float *bias, cons
     a.n_oc_tiles = (sh->OC + FD_MT - 1) / FD_MT;
     if (var == 8) { a.tiles_per_image = 1; a.n_pix_tiles = (sh->N + 3) / 4; }
     else { a.tiles_per_image = (a.P + 32 * var - 1) / (32 * var); a.n_pix_tiles = sh->N * a.tiles_per_image; }
-    a.dbg = getenv("QE_FLATD_DBG") ? atoi(getenv("QE_FLATD_DBG")) : 0;
-    a.stamp = g_mfma_dbg;
-    // persistent form (WIDE variants, >= 4 stages of 32 channels): QE_FLATP=0 keeps one tile per workgroup
-    const bool persistent = var != 8 && !(getenv("QE_FLATP") && atoi(getenv("QE_FLATP")) == 0);
-    if (persistent) {
-        // as many runs as keep 2 workgroups per CU busy (512 resident), a multiple of 8 (one XCD each)
-        int runs = 512 / a.n_oc_tiles / 8 * 8;
-        if (runs < 8) runs = 8;
-        if (const char *e = getenv("QE_FLATP_RUNS")) runs = (atoi(e) + 7) / 8 * 8;
-        a.chunk = (a.n_pix_tiles + runs - 1) / runs;
-        const int n_runs = ((a.n_pix_tiles + a.chunk - 1) / a.chunk + 7) / 8 * 8;
-        const int64_t blocks = (int64_t)n_runs * a.n_oc_tiles;
-        static const bool raised_p = [] {
-            bool ok = true;
-            ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_flatp_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, FpGeom<5>::LDS) == hipSuccess;
-            ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_flatp_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, FpGeom<7>::LDS) == hipSuccess;
-            return ok;
-        }();
-        (void)raised_p;
-        constexpr size_t l5 = FpGeom<5>::LDS, l7 = FpGeom<7>::LDS;
-        if (var == 5) hipLaunchKernelGGL((conv_flatp_kernel<5>), dim3((unsigned)blocks), dim3(256), l5, s, a);
-        else hipLaunchKernelGGL((conv_flatp_kernel<7>), dim3((unsigned)blocks), dim3(256), l7, s, a);
-        QE_LAUNCH_CHECK();
-        return QE_OK;
-    }
     const int64_t per_xcd = ((int64_t)a.n_pix_tiles + 7) / 8;
     a.chunk = (int)(per_xcd < 1 ? 1 : per_xcd);
     if (const char *ci = getenv("QE_CHUNK_IMAGES")) {

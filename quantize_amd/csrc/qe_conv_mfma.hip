@@ -46,7 +46,6 @@ namespace qe {
 struct PrepArgs {
     const uint8_t *w;
     const float *w_scale, *w_zero;
-    const float *x_scale;
     const float *bias;
     int w_bits, w_sign, w_per_tensor;
     int OC, IC, KK, OCP, NG;
@@ -116,7 +115,7 @@ __global__ __launch_bounds__(256) void conv_mfma_prep_kernel(const PrepArgs a)
         if (live) {
             const float sw = a.w_per_tensor ? a.w_scale[0] : a.w_scale[oc];
             const float zw = a.w_per_tensor ? a.w_zero[0] : a.w_zero[oc];
-            alpha = a.x_scale[0] * sw;
+            alpha = sw;                                   // the epilogue multiplies by the activation scale
             zwp = zw - zero_shift(a.w_bits, a.w_sign);
             b = a.bias ? a.bias[oc] : 0.0f;
         }
@@ -168,7 +167,7 @@ __global__ __launch_bounds__(64) void conv_mfma_prep_smallic_kernel(const PrepAr
         if (live) {
             const float sw = a.w_per_tensor ? a.w_scale[0] : a.w_scale[oc];
             const float zw = a.w_per_tensor ? a.w_zero[0] : a.w_zero[oc];
-            alpha = a.x_scale[0] * sw;
+            alpha = sw;                                   // the epilogue multiplies by the activation scale
             zwp = zw - zero_shift(a.w_bits, a.w_sign);
             b = a.bias ? a.bias[oc] : 0.0f;
         }
@@ -197,6 +196,7 @@ struct MfmaPlan {
     int PADW = 0;
     size_t lds = 0;
     size_t wt_bytes = 0, ep_off = 0, ws_off = 0, total = 0;
+    size_t prep_total = 0;     // leading part of the workspace the prep pass fills (x-independent: can be kept across calls)
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -452,12 +452,14 @@ static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits, int w_bits)
                      (sub_env > 0 || p_out <= 256);
     const qe_conv_shape ds = dense_shape(sh);
     MfmaPlan p = make_plan8(sub ? &ds : sh, xb, w_bits);
+    p.prep_total = p.ok ? p.total : 0;
     if (p.ok && sub) {
         p.sub = true;
         p.sub_off = align_up(p.total, 256);
         p.total = p.sub_off + align_up((size_t)ds.N * ds.IC * ds.H * ds.W, 256);
     } else if (sub) {
         p = make_plan8(sh, xb, w_bits);
+        p.prep_total = p.ok ? p.total : 0;
     }
     if (p.ok && expand) {
         p.expand = true;
@@ -565,18 +567,42 @@ size_t mfma_conv_workspace_bytes(const qe_conv_shape *sh, int x_bits, int w_bits
     return p.ok ? p.total : 0;
 }
 
+// bytes of the x-independent part (re-laid-out weights, per-channel constants, tap-sum tables); 0: nothing to prepare
+size_t mfma_conv_prepared_bytes(const qe_conv_shape *sh, int x_bits, int w_bits)
+{
+    const MfmaPlan p = make_plan(sh, x_bits, w_bits);
+    return p.ok ? p.prep_total : 0;
+}
+
+// mode 0: prepare + run (workspace = [prepared part | scratch]); mode 1: prepare only into `prepared`;
+// mode 2: run on a `prepared` buffer filled earlier (workspace = scratch only)
 int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh,
-                     float *out, void *workspace, size_t workspace_bytes, hipStream_t s)
+                     float *out, void *workspace, size_t workspace_bytes, hipStream_t s, int mode, void *prepared,
+                     size_t prepared_bytes)
 {
     const MfmaPlan p = make_plan(sh, x->n_bits, w->n_bits);
     if (!p.ok) return QE_ERR_UNSUPPORTED;
-    if (p.total > 0) {
-        if (workspace == nullptr || workspace_bytes < p.total) return QE_ERR_WORKSPACE;
-        if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return QE_ERR_ARG;
+    uint8_t *wsp = static_cast<uint8_t *>(workspace);       // base the plan's offsets are relative to
+    uint8_t *prep_base = wsp;
+    if (mode == 0) {
+        if (p.total > 0) {
+            if (workspace == nullptr || workspace_bytes < p.total) return QE_ERR_WORKSPACE;
+            if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return QE_ERR_ARG;
+        }
+    } else {
+        if (p.prep_total > 0) {
+            if (prepared == nullptr || prepared_bytes < p.prep_total) return QE_ERR_WORKSPACE;
+            if ((reinterpret_cast<uintptr_t>(prepared) & 15) != 0) return QE_ERR_ARG;
+        }
+        prep_base = static_cast<uint8_t *>(prepared);
+        if (mode == 2 && p.total > p.prep_total) {
+            if (workspace == nullptr || workspace_bytes < p.total - p.prep_total) return QE_ERR_WORKSPACE;
+            if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return QE_ERR_ARG;
+            wsp = static_cast<uint8_t *>(workspace) - p.prep_total;   // scratch offsets start behind the prepared part
+        }
     }
-    uint8_t *wsp = static_cast<uint8_t *>(workspace);
     qe_qparam xe;
-    if (p.expand) {
+    if (p.expand && mode != 1) {
         const int64_t n = (int64_t)sh->N * sh->IC * sh->H * sh->W;
         const int rc = expand_codes_s8(static_cast<const uint8_t *>(x->data), n, x->n_bits, x->sign, wsp + p.xe_off, s);
         if (rc != QE_OK) return rc;
@@ -588,7 +614,10 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     }
     qe_qparam xs;
     qe_conv_shape shd;
-    if (p.sub) {
+    if (p.sub && mode == 1) {
+        shd = dense_shape(sh);
+        sh = &shd;
+    } else if (p.sub) {
         shd = dense_shape(sh);
         const int64_t n_planes = (int64_t)sh->N * sh->IC;
         const bool wide = sh->stride == 2 && (sh->W % 4) == 0 && sh->W >= 16;
@@ -618,23 +647,25 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
         const char *e = getenv("QE_FLATD");
         const int mask = e ? atoi(e) : QE_FLATD_DEFAULT;
         const int bit = var == 7 ? 1 : (var == 5 ? 2 : (var == 8 ? 4 : 0));
-        if (var != 0 && (mask & bit)) return launch_flatd(x, w, bias, sh, out, s);
+        if (var != 0 && (mask & bit)) return mode == 1 ? QE_OK : launch_flatd(x, w, bias, sh, out, s);
     }
 
     PrepArgs pa;
-    pa.w = w->data; pa.w_scale = w->scale; pa.w_zero = w->zero; pa.x_scale = x->scale; pa.bias = bias;
+    pa.w = w->data; pa.w_scale = w->scale; pa.w_zero = w->zero; pa.bias = bias;
     pa.w_bits = w->n_bits; pa.w_sign = w->sign; pa.w_per_tensor = (w->n_param == 1);
     pa.OC = sh->OC; pa.IC = sh->IC; pa.KK = p.KK; pa.OCP = p.OCP; pa.NG = p.NG; pa.KH = sh->KH; pa.KW = sh->KW;
-    pa.wt = reinterpret_cast<int8_t *>(wsp);
-    pa.ep = reinterpret_cast<float *>(wsp + p.ep_off);
-    pa.ws = reinterpret_cast<int *>(wsp + p.ws_off);
-    if ((p.flat || p.flatg) && p.wraw) {
-        // nothing to prepare: the kernel reads the packed tensor and builds its constants itself
+    pa.wt = reinterpret_cast<int8_t *>(prep_base);
+    pa.ep = reinterpret_cast<float *>(prep_base + p.ep_off);
+    pa.ws = reinterpret_cast<int *>(prep_base + p.ws_off);
+    if (((p.flat || p.flatg) && p.wraw) || mode == 2) {
+        // nothing to prepare: the kernel reads the packed tensor and builds its constants itself, or the caller kept
+        // the prepared tables from an earlier qe_conv_prepare (weights do not change between forward passes)
     } else if (p.smallic)
         hipLaunchKernelGGL(conv_mfma_prep_smallic_kernel, dim3(p.OCP), dim3(64), 0, s, pa, (int)sh->KH, (int)sh->KW);
     else
         hipLaunchKernelGGL(conv_mfma_prep_kernel, dim3(p.OCP), dim3(256), 0, s, pa);
     QE_LAUNCH_CHECK();
+    if (mode == 1) return QE_OK;
 
     MfmaArgs a;
     a.x = x->data;

@@ -24,7 +24,7 @@ struct MfmaArgs {
     const float *x_zero;       // per tensor
     int x_bits, x_sign;
     const int8_t *wt;          // [KK][NG][OCP][16]
-    const float *ep;           // [3][OCP]: alpha = sx*sw, zw', bias
+    const float *ep;           // [3][OCP]: sw, zw', bias   (activation scale applied in the epilogue: the table is x-independent)
     const int *ws;             // [OCP][(KH+1)*(KW+1)]: 2-D prefix sums over (kh, kw) of sum_ic a_w; last entry = all taps
     float *out;
     int N, IC, H, W, OC, KH, KW, stride, pad, OH, OW;
@@ -140,10 +140,11 @@ __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW
     const bool need_sw = zxp != 0.0f;
     const int oc_base = ot * MT + wm * 32 + 4 * h;  // + (reg&3) + 8*(reg>>2)
     float al[16], bi[16];
+    const float sx = a.x_scale[0];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int oc = oc_base + (r & 3) + 8 * (r >> 2);
-        al[r] = a.ep[oc];
+        al[r] = sx * a.ep[oc];   // alpha = sx * sw (same product the prep pass used to store)
         bi[r] = a.ep[2 * a.OCP + oc];
     }
     const int OHW = a.OH * a.OW;

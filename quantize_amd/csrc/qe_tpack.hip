@@ -44,10 +44,28 @@ __device__ __forceinline__ unsigned tp_code(T v, float lo, float hi, unsigned of
     return ((unsigned)iv + offset) & mask;
 }
 
-template <typename T, int B>
+// Fused activation quantisation: the Quantizer's
+//   q = round(x / scale - zero).clamp(qmin, qmax)      (modelzoo/modules/quantizer.py:31, :215; zero in the MODULE's
+// convention, i.e. subtracted here and added back on dequantisation) in front of the packer, so the fp32 integer-valued
+// tensor the reference materialises between Quantizer and tpack (4 B/element written + read again) never exists.
+// Same fp32 operations in the same order as torch: IEEE division, subtraction, round-half-even, clamp (NaN passes
+// through the clamp and trips the range flag like it trips CHECK_RANGE).
+struct TpQuant {
+    const float *scale, *zero;   // 1 element, or one per channel
+    float qmin, qmax;
+    uint32_t inner, n_ch;        // per channel: channel of element i = (i / inner) % n_ch
+};
+__device__ __forceinline__ float tp_quantize(float v, float sc, float zr, float qmin, float qmax)
+{
+    const float r = rintf(v / sc - zr);
+    return (r != r) ? r : fminf(fmaxf(r, qmin), qmax);
+}
+
+// QM: 0 = plain tpack, 1 = quantise with per-tensor scale/zero, 2 = per channel (T = float for 1 and 2)
+template <typename T, int B, int QM>
 __global__ __launch_bounds__(TP_THREADS) void tpack_kernel(
     const T *__restrict__ x, uint8_t *__restrict__ out, int64_t n, int64_t n_out_bytes,
-    unsigned offset, float lo, float hi, int32_t *__restrict__ status, int in_aligned, int out_aligned)
+    unsigned offset, float lo, float hi, int32_t *__restrict__ status, int in_aligned, int out_aligned, const TpQuant q)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_codes[TP_TILE / 4];    // 8 KiB
     __shared__ __attribute__((aligned(16))) uint32_t s_words[TP_THREADS * B]; // <= 8 KiB
@@ -57,25 +75,46 @@ __global__ __launch_bounds__(TP_THREADS) void tpack_kernel(
     constexpr unsigned mask = (1u << B) - 1u;
     bool bad = false;
 
+    float sc1 = 1.0f, zr1 = 0.0f;
+    if constexpr (QM == 1) { sc1 = q.scale[0]; zr1 = q.zero[0]; }
+    // element -> code: the Quantizer in front of the packer when QM != 0 (ch = channel of the element)
+    auto code = [&](T v, uint32_t ch) __attribute__((always_inline)) -> unsigned {
+        if constexpr (QM == 0) return tp_code<T>(v, lo, hi, offset, mask, bad);
+        else if constexpr (QM == 1) return tp_code<float>(tp_quantize((float)v, sc1, zr1, q.qmin, q.qmax), lo, hi, offset, mask, bad);
+        else return tp_code<float>(tp_quantize((float)v, q.scale[ch], q.zero[ch], q.qmin, q.qmax), lo, hi, offset, mask, bad);
+    };
+
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t base = tile * TP_TILE;
+        // per channel: plane and offset inside it of the tile's first element, once per tile in 64 bits; 32 bits from there
+        uint32_t pl0 = 0, r0 = 0;
+        if constexpr (QM == 2) {
+            const int64_t pl = base / (int64_t)q.inner;
+            r0 = (uint32_t)(base - pl * (int64_t)q.inner);
+            pl0 = (uint32_t)(pl % (int64_t)q.n_ch);
+        }
+        auto chan = [&](uint32_t o) __attribute__((always_inline)) -> uint32_t {   // channel of element base + o
+            if constexpr (QM == 2) return (pl0 + (r0 + o) / q.inner) % q.n_ch; else return 0u;
+        };
 
         // (1) coalesced loads: iteration k covers elements base + k*1024 + 4*tid .. +3
 #pragma unroll
         for (int k = 0; k < TP_EPT / 4; ++k) {
-            const int64_t e = base + (int64_t)k * (TP_THREADS * 4) + tid * 4;
+            const uint32_t o = (uint32_t)(k * (TP_THREADS * 4) + tid * 4);
+            const int64_t e = base + o;
             unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-            if (e + 3 < n && in_aligned) {
+            if (e + 3 < n && in_aligned && (QM != 2 || (q.inner & 3u) == 0)) {   // 4 elements of one channel
                 const Vec4<T> v = *reinterpret_cast<const Vec4<T> *>(x + e);
-                c0 = tp_code<T>(v.v[0], lo, hi, offset, mask, bad);
-                c1 = tp_code<T>(v.v[1], lo, hi, offset, mask, bad);
-                c2 = tp_code<T>(v.v[2], lo, hi, offset, mask, bad);
-                c3 = tp_code<T>(v.v[3], lo, hi, offset, mask, bad);
+                const uint32_t ch = chan(o);
+                c0 = code(v.v[0], ch);
+                c1 = code(v.v[1], ch);
+                c2 = code(v.v[2], ch);
+                c3 = code(v.v[3], ch);
             } else {
-                if (e + 0 < n) c0 = tp_code<T>(x[e + 0], lo, hi, offset, mask, bad);
-                if (e + 1 < n) c1 = tp_code<T>(x[e + 1], lo, hi, offset, mask, bad);
-                if (e + 2 < n) c2 = tp_code<T>(x[e + 2], lo, hi, offset, mask, bad);
-                if (e + 3 < n) c3 = tp_code<T>(x[e + 3], lo, hi, offset, mask, bad);
+                if (e + 0 < n) c0 = code(x[e + 0], chan(o));
+                if (e + 1 < n) c1 = code(x[e + 1], chan(o + 1));
+                if (e + 2 < n) c2 = code(x[e + 2], chan(o + 2));
+                if (e + 3 < n) c3 = code(x[e + 3], chan(o + 3));
             }
             s_codes[k * TP_THREADS + tid] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
         }
@@ -230,8 +269,9 @@ __global__ __launch_bounds__(TP_THREADS) void tunpack_kernel(
     }
 }
 
-template <typename T>
-static int launch_tpack_t(const void *x, int64_t n, int n_bits, int sign, uint8_t *out, int32_t *status, hipStream_t s)
+template <typename T, int QM = 0>
+static int launch_tpack_t(const void *x, int64_t n, int n_bits, int sign, uint8_t *out, int32_t *status, hipStream_t s,
+                          const TpQuant q = TpQuant{nullptr, nullptr, 0.0f, 0.0f, 1u, 1u})
 {
     const int64_t n_out = qe_packed_nbytes(n, n_bits);
     const unsigned offset = sign ? (1u << (n_bits - 1)) : 0u;  // tpack.cu:108-111
@@ -245,8 +285,8 @@ static int launch_tpack_t(const void *x, int64_t n, int n_bits, int sign, uint8_
     const T *xp = static_cast<const T *>(x);
 #define QE_TP_CASE(BITS)                                                                          \
     case BITS:                                                                                    \
-        hipLaunchKernelGGL((tpack_kernel<T, BITS>), dim3(blocks), dim3(TP_THREADS), 0, s, xp, out, \
-                           n, n_out, offset, lo, hi, status, in_al, out_al);                      \
+        hipLaunchKernelGGL((tpack_kernel<T, BITS, QM>), dim3(blocks), dim3(TP_THREADS), 0, s, xp, out, \
+                           n, n_out, offset, lo, hi, status, in_al, out_al, q);                   \
         break;
     switch (n_bits) {
         QE_TP_CASE(1) QE_TP_CASE(2) QE_TP_CASE(3) QE_TP_CASE(4)
@@ -286,6 +326,24 @@ extern "C" int qe_tpack(const void *x, int dtype, int64_t n, int n_bits, int sig
         case QE_F64: return launch_tpack_t<double>(x, n, n_bits, sign, out, status, s);
         default: return QE_ERR_DTYPE;
     }
+}
+
+extern "C" int qe_quantize_pack(const float *x, int64_t n, const float *scale, const float *zero, int32_t n_param,
+                                int64_t inner, float qmin, float qmax, int n_bits, int sign, uint8_t *out,
+                                int32_t *status, qe_stream_t stream)
+{
+    using namespace qe;
+    if (!(n_bits > 0 && n_bits <= 8)) return QE_ERR_NBITS;
+    if (n < 0 || n_param < 1) return QE_ERR_ARG;
+    if (n == 0) return QE_OK;
+    if (x == nullptr || out == nullptr || scale == nullptr || zero == nullptr) return QE_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TpQuant q{scale, zero, qmin, qmax, 1u, 1u};
+    if (n_param == 1) return launch_tpack_t<float, 1>(x, n, n_bits, sign, out, status, s, q);
+    if (inner < 1 || inner >= (1ll << 31) - TP_TILE) return QE_ERR_ARG;   // 32-bit offsets inside a tile
+    q.inner = (uint32_t)inner;
+    q.n_ch = (uint32_t)n_param;
+    return launch_tpack_t<float, 2>(x, n, n_bits, sign, out, status, s, q);
 }
 
 namespace qe {

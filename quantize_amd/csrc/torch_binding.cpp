@@ -22,6 +22,13 @@
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
+#include <hip/hip_runtime_api.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <optional>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/quant_engine.h"
@@ -74,9 +81,66 @@ struct Des {
     int64_t numel = 1;
 };
 
+// ------------------------------------------------------------------------------------------
+// Host-side caches.  A packed layer hands the SAME des / weight / scale tensors to the
+// operator on every forward pass (buffers registered by pack(), quantconv2d.py:187-192), so what the host derives from
+// them is kept between calls: the parsed description (saves the blocking device->host copy the reference pays ten
+// times per call, quantconv2d.cu:191-207) and the prepared weight tables of qe_conv_prepare (saves the re-layout
+// launch).  An entry is keyed on the tensor object (TensorImpl), its version counter, data pointer and size, and is
+// dropped once the tensor object is gone.  `tensor.data = other` swaps storage without bumping the version: the data
+// pointer in the key catches that unless the allocator hands the new storage the old address -- after such surgery on
+// a packed module call quant_engine.clear_cache() (or run with QE_NO_CACHE=1, which disables both caches).
+// ------------------------------------------------------------------------------------------
+struct TensorKey {
+    std::optional<c10::weak_intrusive_ptr<c10::TensorImpl>> impl;   // weak: the cache never keeps a tensor alive
+    const void *ptr = nullptr;
+    int64_t numel = 0;
+    uint32_t version = 0;
+    bool matches(const torch::Tensor &t) const
+    {
+        return impl.has_value() && !impl->expired() && impl->_unsafe_get_target() == t.unsafeGetTensorImpl() &&
+               ptr == t.data_ptr() && numel == t.numel() && version == t._version();
+    }
+    static TensorKey of(const torch::Tensor &t)
+    {
+        TensorKey k;
+        k.impl.emplace(t.getIntrusivePtr());
+        k.ptr = t.data_ptr();
+        k.numel = t.numel();
+        k.version = (uint32_t)t._version();
+        return k;
+    }
+};
+bool cache_enabled()
+{
+    static const bool on = !(std::getenv("QE_NO_CACHE") && std::atoi(std::getenv("QE_NO_CACHE")) != 0);
+    return on;
+}
+bool cacheable(const torch::Tensor &t) { return cache_enabled() && t.defined() && !t.is_inference(); }
+std::mutex g_cache_mutex;
+struct DesEntry { TensorKey key; Des des; };
+std::unordered_map<const void *, DesEntry> g_des_cache;
+int64_t g_des_hits = 0, g_des_misses = 0, g_prep_hits = 0, g_prep_misses = 0;
+
+Des read_des_uncached(const torch::Tensor &des);
+
 // One device->host copy of the whole description (the reference issues one blocking
-// .item() per field: quantconv2d.cu:191-207, tpack.cu:435-474).
+// .item() per field: quantconv2d.cu:191-207, tpack.cu:435-474), and none at all when this
+// des tensor has been parsed before.
 Des read_des(const torch::Tensor &des)
+{
+    if (!cacheable(des) || !des.device().is_cuda()) return read_des_uncached(des);
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    auto it = g_des_cache.find(des.unsafeGetTensorImpl());
+    if (it != g_des_cache.end() && it->second.key.matches(des)) { ++g_des_hits; return it->second.des; }
+    ++g_des_misses;
+    if (g_des_cache.size() > 8192) g_des_cache.clear();
+    DesEntry e{TensorKey::of(des), read_des_uncached(des)};
+    g_des_cache[des.unsafeGetTensorImpl()] = e;
+    return e.des;
+}
+
+Des read_des_uncached(const torch::Tensor &des)
 {
     auto d = des.to(torch::kCPU, torch::kLong).contiguous();
     const int64_t *p = d.data_ptr<int64_t>();
@@ -218,6 +282,75 @@ qe_qparam make_qparam(const torch::Tensor &data, const Des &d, const torch::Tens
     return q;
 }
 
+struct PrepEntry {
+    TensorKey w, s, z, b;
+    bool has_bias = false;
+    int x_bits = 0, w_bits = 0, w_sign = 0;
+    qe_conv_shape sh{};
+    torch::Tensor prepared;
+    qe_stream_t stream = nullptr;
+};
+std::unordered_map<const void *, PrepEntry> g_prep_cache;
+
+void clear_cache()
+{
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    g_des_cache.clear();
+    g_prep_cache.clear();
+}
+std::vector<int64_t> cache_stats()
+{
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    return {g_des_hits, g_des_misses, g_prep_hits, g_prep_misses, (int64_t)g_des_cache.size(), (int64_t)g_prep_cache.size()};
+}
+
+// ------------------------------------------------------------------------------------------
+// quantize_pack (extension): Quantizer + tpack in one pass.
+//   reference: modelzoo/modules/quantizer.py:31,213-226 then engine.tpack.  scale/zero in the module's convention
+//   (q = round(x / scale - zero)); per channel when they hold x.size(1) elements (activations (N, C, ...)) or
+//   x.size(0) elements with channel_dim = 0 (weights (C, ...)).  Returns [packed uint8, des int32] like tpack.
+// ------------------------------------------------------------------------------------------
+std::vector<torch::Tensor> quantize_pack(torch::Tensor x, torch::Tensor scale, torch::Tensor zero, double qmin, double qmax,
+                                         int n_bits, bool sign, int channel_dim)
+{
+    CHECK_NBITS(n_bits);
+    CHECK_CONTIGUOUS(x);
+    CHECK_FLOAT(x);
+    TORCH_CHECK(x.numel() > 0, "quantize_pack: empty input");
+    TORCH_CHECK(scale.numel() == zero.numel() && scale.numel() >= 1, "scale and zero must have the same number of elements");
+    TORCH_CHECK(scale.scalar_type() == torch::kFloat && zero.scalar_type() == torch::kFloat, "scale/zero must be float tensors");
+    int64_t inner = 1;
+    if (scale.numel() > 1) {
+        TORCH_CHECK(channel_dim >= 0 && channel_dim < x.dim() && x.size(channel_dim) == scale.numel(),
+                    "per-channel scale must hold x.size(channel_dim) elements");
+        for (int64_t d = channel_dim + 1; d < x.dim(); ++d) inner *= x.size(d);
+    }
+    std::vector<int32_t> dv;
+    dv.push_back(n_bits);
+    dv.push_back(sign ? 1 : 0);
+    for (auto sz : x.sizes()) dv.push_back((int32_t)sz);
+    if (!x.device().is_cuda()) {   // host tensors: the module's own arithmetic, then the host packer
+        std::vector<int64_t> bshape(x.dim(), 1);
+        if (scale.numel() > 1) bshape[channel_dim] = scale.numel();
+        auto q = (x / scale.reshape(bshape) - zero.reshape(bshape)).round().clamp(qmin, qmax);
+        return tpack_host(q.contiguous(), n_bits, sign);
+    }
+    CHECK_CUDA(scale);
+    CHECK_CUDA(zero);
+    CHECK_CONTIGUOUS(scale);
+    CHECK_CONTIGUOUS(zero);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+    const int64_t n = x.numel();
+    auto x_out = torch::empty({qe_packed_nbytes(n, n_bits)}, torch::dtype(torch::kByte).device(x.device()));
+    auto status = torch::zeros({1}, torch::dtype(torch::kInt).device(x.device()));
+    check_status(qe_quantize_pack(x.data_ptr<float>(), n, scale.data_ptr<float>(), zero.data_ptr<float>(), (int32_t)scale.numel(),
+                                  inner, (float)qmin, (float)qmax, n_bits, sign ? 1 : 0, x_out.data_ptr<uint8_t>(),
+                                  status.data_ptr<int32_t>(), current_stream(x)),
+                 "quantize_pack");
+    TORCH_CHECK(status.item<int>() == 0, "The input tensor is out of range.");
+    return {x_out, torch::tensor(dv, torch::dtype(torch::kInt)).to(x.device())};
+}
+
 // ------------------------------------------------------------------------------------------
 // quantconv2d  (reference: functions/quantconv2d.cu:164-264, funcs.h:113-124)
 // ------------------------------------------------------------------------------------------
@@ -281,6 +414,58 @@ torch::Tensor quantconv2d(const torch::Tensor &input, const torch::Tensor &input
     auto output = torch::empty({sh.N, sh.OC, OH, OW}, torch::dtype(torch::kFloat32).device(input.device()));
     const qe_qparam xq = make_qparam(input, xd, input_scale, input_zero);
     const qe_qparam wq = make_qparam(weight, wd, weight_scale, weight_zero);
+
+    // Prepared weight tables: built once per (weight, scale, zero, bias) tensor set and kept while those tensors live
+    // unchanged; later calls run only the convolution (qe_quantconv2d_prepared).  Results are bit-identical.
+    const size_t prep_bytes = qe_conv_prepared_bytes(&sh, xd.n_bits, wd.n_bits);
+    const bool use_cache = prep_bytes > 0 && qe_quantconv2d_path(&sh, &xq, &wq) == 1 && cacheable(weight) &&
+                           cacheable(weight_scale) && cacheable(weight_zero) && (!bias.has_value() || cacheable(bias.value()));
+    if (use_cache) {
+        torch::Tensor prepared;
+        {
+            std::lock_guard<std::mutex> lock(g_cache_mutex);
+            auto it = g_prep_cache.find(weight.unsafeGetTensorImpl());
+            if (it != g_prep_cache.end()) {
+                const PrepEntry &e = it->second;
+                const bool hit = e.w.matches(weight) && e.s.matches(weight_scale) && e.z.matches(weight_zero) &&
+                                 e.has_bias == bias.has_value() && (!e.has_bias || e.b.matches(bias.value())) &&
+                                 e.x_bits == xd.n_bits && e.w_bits == wd.n_bits && e.w_sign == wd.sign &&
+                                 std::memcmp(&e.sh, &sh, sizeof(sh) - 0) == 0 && (size_t)e.prepared.numel() == prep_bytes;
+                if (hit) { prepared = e.prepared; ++g_prep_hits; }
+            }
+        }
+        if (!prepared.defined()) {
+            prepared = torch::empty({(int64_t)prep_bytes}, torch::dtype(torch::kByte).device(input.device()));
+            check_status(qe_conv_prepare(&wq, bias_ptr, &sh, xd.n_bits, prepared.data_ptr(), prep_bytes, current_stream(input)),
+                         "quantconv2d (prepare)");
+            // the tables are filled in stream order; other streams using the entry later would need an event --
+            // the entry therefore remembers its stream and is only reused on it
+            PrepEntry e;
+            e.w = TensorKey::of(weight); e.s = TensorKey::of(weight_scale); e.z = TensorKey::of(weight_zero);
+            e.has_bias = bias.has_value();
+            if (e.has_bias) e.b = TensorKey::of(bias.value());
+            e.x_bits = xd.n_bits; e.w_bits = wd.n_bits; e.w_sign = wd.sign; e.sh = sh; e.prepared = prepared;
+            e.stream = current_stream(input);
+            std::lock_guard<std::mutex> lock(g_cache_mutex);
+            ++g_prep_misses;
+            if (g_prep_cache.size() > 4096) g_prep_cache.clear();
+            g_prep_cache[weight.unsafeGetTensorImpl()] = e;
+        } else {
+            std::lock_guard<std::mutex> lock(g_cache_mutex);
+            auto it = g_prep_cache.find(weight.unsafeGetTensorImpl());
+            if (it != g_prep_cache.end() && it->second.stream != current_stream(input)) {
+                // another stream: order it behind the stream that filled the tables (they are never rewritten)
+                TORCH_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(it->second.stream)) == hipSuccess, "hipStreamSynchronize failed");
+                it->second.stream = current_stream(input);
+            }
+        }
+        const size_t sc_bytes = qe_quantconv2d_prepared_workspace_bytes(&sh, xd.n_bits, wd.n_bits);
+        auto scratch = torch::empty({(int64_t)sc_bytes}, torch::dtype(torch::kByte).device(input.device()));
+        check_status(qe_quantconv2d_prepared(&xq, &wq, bias_ptr, &sh, prepared.data_ptr(), prep_bytes, output.data_ptr<float>(),
+                                             sc_bytes ? scratch.data_ptr() : nullptr, sc_bytes, current_stream(input)),
+                     "quantconv2d");
+        return output;
+    }
     const size_t ws_bytes = qe_quantconv2d_workspace_bytes(&sh, xd.n_bits, wd.n_bits);
     auto workspace = torch::empty({(int64_t)ws_bytes}, torch::dtype(torch::kByte).device(input.device()));
     check_status(qe_quantconv2d(&xq, &wq, bias_ptr, &sh, output.data_ptr<float>(),
@@ -483,6 +668,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           "quantconv2d(x, x_des, x_scale, x_zero, w, w_des, w_scale, w_zero, bias, stride, padding) -> fp32 NCHW.");
     m.def("quantconv2d_float_input", &quantconv2d_float_input,
           "quantconv2d_float_input(x_fp32, w, w_des, w_scale, w_zero, bias, stride, padding) -> fp32 NCHW.");
+    // extensions (no counterpart in the reference's module)
+    m.def("quantize_pack", &quantize_pack,
+          "quantize_pack(x_fp32, scale, zero, qmin, qmax, n_bits, sign, channel_dim) -> [packed, des]: "
+          "round(x / scale - zero).clamp(qmin, qmax) packed like tpack, in one pass.");
+    m.def("clear_cache", &clear_cache, "drop the cached descriptions and prepared weight tables");
+    m.def("cache_stats", &cache_stats, "[des hits, des misses, prepared hits, prepared misses, des entries, prepared entries]");
     m.attr("__qe_version__") = qe_version();
     m.attr("__qe_arch__") = qe_target_arch();
 }
