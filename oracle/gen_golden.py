@@ -353,6 +353,7 @@ def gen_g4():
         out[key + "_a_scale"] = a_scale.numpy().reshape(-1)
         out[key + "_a_zero_py"] = a_zero.numpy().reshape(-1)   # PYTHON convention: (q + zero) * scale
         out[key + "_a_bits_sign"] = np.array([a_set["n_bits"], int(qx.min() < 0)], np.int32)
+        out[key + "_a_qmin_qmax"] = np.array([float(sd["a_quantizer.qmin"]), float(sd["a_quantizer.qmax"])], np.float32)
         out[key + "_weight_packed"] = sd["weight"].numpy()
         out[key + "_w_des"] = sd["w_des"].numpy()
         out[key + "_w_scale"] = sd["w_scale"].numpy()          # (C,1,1,1) or (1,1,1,1)
@@ -496,6 +497,7 @@ def gen_g6():
         out[key + "_a_scale"] = a_scale.numpy().reshape(-1)
         out[key + "_a_zero_py"] = a_zero.numpy().reshape(-1)    # PYTHON convention (q + zero) * scale
         out[key + "_a_bits_sign"] = np.array([a_set["n_bits"], int(qx.min() < 0)], np.int32)
+        out[key + "_a_qmin_qmax"] = np.array([float(sd["a_quantizer.qmin"]), float(sd["a_quantizer.qmax"])], np.float32)
         out[key + "_weight_packed"] = sd["weight"].numpy()
         out[key + "_w_des"] = sd["w_des"].numpy()
         out[key + "_w_scale"] = sd["w_scale"].numpy()

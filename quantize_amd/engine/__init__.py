@@ -19,5 +19,11 @@ conv2d = _qe.conv2d
 quantconv2d = _qe.quantconv2d
 quantconv2d_float_input = _qe.quantconv2d_float_input
 
+# extensions of this engine (not part of the reference's facade, hence not in __all__): fused Quantizer + tpack, and
+# the host-side caches of the binding
+quantize_pack = _qe.quantize_pack
+clear_cache = _qe.clear_cache
+cache_stats = _qe.cache_stats
+
 __all__ = ["tpack", "tunpack", "linear", "quantlinear", "quantlinear_float_input",
            "conv2d", "quantconv2d", "quantconv2d_float_input"]

@@ -1,0 +1,121 @@
+"""Opt-in wiring of packed Quant modules to the operator path.
+
+The reference's packed forward still dequantises and calls F.conv2d / F.linear; the operator call is commented out
+(modelzoo/modules/quantconv2d.py:198-210, quantlinear.py:150-161) and the runners' packing loop with it
+(runner/ptq.py:106-114).  These two classes are what those call sites become on this engine.  They take the STATE of a
+packed module -- tensors only, exactly the state_dict entries pack() leaves behind (quantconv2d.py:187-192:
+weight = packed uint8 stream, w_des, w_scale, w_zero, bias, a_quantizer.{scale, zero, qmin, qmax}) -- so no reference
+Python is needed where they run, and they keep the weights PACKED (no tunpack on load, the TODO of quantconv2d.py:230-233).
+
+Sign conventions, reconciled here and nowhere else:
+  * the modules dequantise as (q + zero) * scale (quantizer.py:218);
+  * quantconv2d / quantconv2d_float_input / quantlinear_float_input take (q - zero) * scale -> zeros are negated;
+  * quantlinear (packed x packed) takes (q + zero) (quantlinear.cu:115,120)             -> zeros pass unchanged.
+
+Two routes per layer, as the operator's dtype dispatch offers them (quantconv2dop.py:88-95):
+  route="packed"  activations are quantised AND packed on the device in one pass (engine.quantize_pack: the
+                  Quantizer's round(x / scale - zero).clamp(qmin, qmax) + tpack) and meet the packed weights on the
+                  int8 MFMA kernels;
+  route="float"   the form the reference's TODO names first ("only support float input and packed weight"): the
+                  fake-quantised fp32 activations (q + zero) * scale with the packed weights.
+"""
+import torch
+
+from . import engine
+from .operator import quantconv2d_forward, quantlinear_forward
+
+
+def _first(v):
+    return int(v[0]) if isinstance(v, (tuple, list)) else int(v)
+
+
+class _PackedBase:
+    def __init__(self, weight, w_des, w_scale, w_zero, bias, a_scale, a_zero, a_qmin, a_qmax, a_bits, a_signed):
+        assert weight.dtype == torch.uint8 and weight.dim() == 1, "weight must be the packed 1-D uint8 stream pack() stores"
+        self.weight, self.w_des, self.bias = weight, w_des, bias
+        self.w_scale, self.w_zero = w_scale.contiguous(), w_zero.contiguous()            # module convention (q + zero)
+        self.a_scale = a_scale.reshape(-1).contiguous().float()
+        self.a_zero = a_zero.reshape(-1).contiguous().float()
+        self.a_qmin, self.a_qmax = float(a_qmin), float(a_qmax)
+        self.a_bits, self.a_signed = int(a_bits), bool(a_signed)
+        self._neg_w_zero = (-self.w_zero).contiguous()       # kernel convention, built once (tensors stay alive: cache keys)
+        self._neg_a_zero = (-self.a_zero).contiguous()
+
+    @classmethod
+    def _state(cls, sd, prefix):
+        g = lambda k: sd[prefix + k]
+        qmin, qmax = float(g("a_quantizer.qmin")), float(g("a_quantizer.qmax"))
+        n_levels = int(round(qmax - qmin)) + 1
+        a_bits = max(1, (n_levels - 1).bit_length())
+        return dict(weight=g("weight"), w_des=g("w_des"), w_scale=g("w_scale"), w_zero=g("w_zero"),
+                    bias=sd.get(prefix + "bias"), a_scale=g("a_quantizer.scale"), a_zero=g("a_quantizer.zero"),
+                    a_qmin=qmin, a_qmax=qmax, a_bits=a_bits, a_signed=qmin < 0)
+
+    def to(self, device):
+        for k, v in list(vars(self).items()):
+            if torch.is_tensor(v):
+                setattr(self, k, v.to(device))
+        return self
+
+    def quantize(self, x, channel_dim=1):
+        """Quantizer.simulate in packed mode (quantizer.py:215,226) fused with tpack: (packed, des)."""
+        return engine.quantize_pack(x.contiguous(), self.a_scale, self.a_zero, self.a_qmin, self.a_qmax, self.a_bits,
+                                    self.a_signed, channel_dim)
+
+    def fake_quant(self, x, channel_dim=1):
+        """(q + zero) * scale in fp32: what the reference's packed forward feeds F.conv2d (quantconv2d.py:207-208)."""
+        shape = [1] * x.dim()
+        if self.a_scale.numel() > 1:
+            shape[channel_dim] = -1
+        s, z = self.a_scale.view(shape), self.a_zero.view(shape)
+        q = (x / s - z).round().clamp(self.a_qmin, self.a_qmax)
+        return ((q + z) * s).contiguous()
+
+
+class PackedConv2d(_PackedBase):
+    """A packed QuantConv2d's forward on the engine: quantconv2d_forward(x, (weight, w_des, w_scale, w_zero), bias,
+    stride, padding, dilation, groups) -- the commented call of quantconv2d.py:204-206 -- with the activation operand
+    produced on the device."""
+
+    def __init__(self, *, stride=1, padding=0, **state):
+        super().__init__(**state)
+        self.stride, self.padding = _first(stride), _first(padding)
+
+    @classmethod
+    def from_state_dict(cls, state_dict, prefix="", stride=1, padding=0):
+        return cls(stride=stride, padding=padding, **cls._state(state_dict, prefix))
+
+    def __call__(self, x, route="packed"):
+        w = (self.weight, self.w_des, self.w_scale, self._neg_w_zero)
+        if route == "packed":
+            xq, x_des = self.quantize(x)
+            return quantconv2d_forward((xq, x_des, self.a_scale, self._neg_a_zero), w, self.bias,
+                                       (self.stride, self.stride), (self.padding, self.padding), (1, 1), 1)
+        if route == "float":
+            return quantconv2d_forward(self.fake_quant(x), w, self.bias, self.stride, self.padding, 1, 1)
+        raise ValueError("route must be 'packed' or 'float'")
+
+
+class PackedLinear(_PackedBase):
+    """A packed QuantLinear's forward on the engine (quantlinear.py:150-161).  The packed x packed kernel of the
+    reference indexes the activation scale by batch ROW (quantlinear.cu:96), so a per-tensor scale is what the modules'
+    'layer' granularity provides; inputs with leading dimensions are flattened to (rows, in_features)."""
+
+    @classmethod
+    def from_state_dict(cls, state_dict, prefix=""):
+        return cls(**cls._state(state_dict, prefix))
+
+    def __call__(self, x, route="packed"):
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1])
+        ws, wz = self.w_scale.reshape(-1), self.w_zero.reshape(-1)
+        if route == "packed":
+            assert self.a_scale.numel() == 1, "quantlinear takes a per-tensor or per-row activation scale"
+            xq, x_des = self.quantize(x2, channel_dim=x2.dim() - 1)
+            y = quantlinear_forward((xq, x_des, self.a_scale, self.a_zero), (self.weight, self.w_des, ws, wz), self.bias)
+        elif route == "float":
+            y = quantlinear_forward(self.fake_quant(x2, channel_dim=x2.dim() - 1),
+                                    (self.weight, self.w_des, ws, self._neg_w_zero.reshape(-1)), self.bias)
+        else:
+            raise ValueError("route must be 'packed' or 'float'")
+        return y.reshape(*lead, y.shape[-1])
