@@ -50,6 +50,9 @@ def parse_args():
     ap.add_argument("--cpu-images", type=int, default=16, help="images of the CPU-baseline sample (about 15 s on 16 cores)")
     ap.add_argument("--cpu-fallback-images", type=int, default=32,
                     help="images of the reference-fallback sample (torch-CPU F.conv2d on dequantised tensors)")
+    ap.add_argument("--float-input", action="store_true",
+                    help="the quantconv2d_float_input operator instead: fp32 NCHW activations x packed weights on the same 53-layer "
+                         "stack (22.32 GB algorithmic per batch-256); reported under its own metric name, never as the headline")
     ap.add_argument("--per-call-prepare", action="store_true",
                     help="re-lay-out the 3x3 / stem weights inside every call (qe_quantconv2d, as round 1 timed it) instead of "
                          "once per layer at set-up (qe_conv_prepare + qe_quantconv2d_prepared: a packed layer's weights do not "
@@ -68,16 +71,37 @@ class Layer:
         self.idx, self.spec, self.N = idx, spec, N
         s = resnet50.synth_layer(spec, idx, N, dev, x_bits=args.a_bits, w_bits=args.w_bits,
                                  asymmetric=args.asymmetric, rank=rank)
-        self.xp, st = capi.tpack(s["qx"].reshape(-1), args.a_bits, s["x_sign"])
+        self.float_input = bool(getattr(args, "float_input", False))
         self.wp, st2 = capi.tpack(s["qw"].reshape(-1), args.w_bits, s["w_sign"])
-        assert int(st.item()) == 0 and int(st2.item()) == 0
+        assert int(st2.item()) == 0
+        if self.float_input:
+            # fp32 activations ~ N(0, 0.5), seed 5000 + idx (+ rank): the operator takes them as they are (no quantisation)
+            gx = torch.Generator(device=dev)
+            gx.manual_seed(5000 + idx + 1000003 * rank)
+            self.xf = torch.randn((N, spec.IC, spec.H, spec.H), generator=gx, device=dev) * 0.5
+            self.xp = None
+        else:
+            self.xp, st = capi.tpack(s["qx"].reshape(-1), args.a_bits, s["x_sign"])
+            assert int(st.item()) == 0
+        del s["qx"]
         self.sx, self.zx, self.sw, self.zw, self.bias = s["sx"], s["zx"], s["sw"].reshape(-1), s["zw"].reshape(-1), s["bias"]
         self.x_sign = s["x_sign"]
         self.sh = capi.conv_shape(N, spec.IC, spec.H, spec.H, spec.OC, spec.K, spec.K, spec.stride, spec.pad)
-        self.xq = capi.qparam(self.xp, args.a_bits, s["x_sign"], self.sx, self.zx)
         self.wq = capi.qparam(self.wp, args.w_bits, True, self.sw, self.zw)
         oh, ow = capi.out_hw(self.sh)
         self.out = torch.empty((N, spec.OC, oh, ow), dtype=torch.float32, device=dev)
+        if self.float_input:
+            L = capi.lib()
+            bias_p = ctypes.c_void_p(self.bias.data_ptr()) if self.bias is not None else None
+            self.path = capi.float_input_path(self.sh, self.wq)
+            self.prepared = capi.conv_f32_prepare(self.wq, self.bias, self.sh)     # once, outside the timed region
+            self.bytes = resnet50.algorithmic_bytes(spec, N, args.a_bits, args.w_bits, float_input=True)
+            self.ops = 2 * resnet50.macs_per_image(spec) * N
+            pp = ctypes.c_void_p(self.prepared.data_ptr()) if self.prepared.numel() else None
+            self._call = (L.qe_quantconv2d_float_input_prepared, ctypes.c_void_p(self.xf.data_ptr()), ctypes.byref(self.wq), bias_p,
+                          ctypes.byref(self.sh), pp, ctypes.c_size_t(self.prepared.numel()), ctypes.c_void_p(self.out.data_ptr()))
+            return
+        self.xq = capi.qparam(self.xp, args.a_bits, s["x_sign"], self.sx, self.zx)
         L = capi.lib()
         bias_p = ctypes.c_void_p(self.bias.data_ptr()) if self.bias is not None else None
         self.prepared = None
@@ -106,7 +130,7 @@ class Layer:
         f = self._call
         rc = f[0](*f[1:], stream_ptr)
         if rc != 0:
-            raise RuntimeError("qe_quantconv2d failed on layer %s: %d" % (self.spec.name, rc))
+            raise RuntimeError("conv call failed on layer %s: %d" % (self.spec.name, rc))
 
 
 def usable_cores():
@@ -137,13 +161,19 @@ def cpu_fallback_baseline(layers, args, torch):
     for L in layers:
         sp = L.spec
         n_x = n_img * sp.IC * sp.H * sp.H
+        if L.float_input:
+            qw = capi.tunpack(L.wp, sp.OC * sp.IC * sp.K * sp.K, args.w_bits, True).reshape(sp.OC, sp.IC, sp.K, sp.K).cpu()
+            work.append((L.xf[:n_img].cpu(), None, None, qw, L.sw.cpu().reshape(-1, 1, 1, 1), L.zw.cpu().reshape(-1, 1, 1, 1),
+                         None if L.bias is None else L.bias.cpu(), sp.stride, sp.pad))
+            continue
         qx = capi.tunpack(L.xp[: (n_x * args.a_bits + 7) // 8], n_x, args.a_bits, L.x_sign).reshape(n_img, sp.IC, sp.H, sp.H).cpu()
         qw = capi.tunpack(L.wp, sp.OC * sp.IC * sp.K * sp.K, args.w_bits, True).reshape(sp.OC, sp.IC, sp.K, sp.K).cpu()
         work.append((qx, L.sx.cpu(), L.zx.cpu(), qw, L.sw.cpu().reshape(-1, 1, 1, 1), L.zw.cpu().reshape(-1, 1, 1, 1),
                      None if L.bias is None else L.bias.cpu(), sp.stride, sp.pad))
     def run():
         for qx, sx, zx, qw, sw, zw, b, st, pd in work:
-            F.conv2d((qx.float() - zx) * sx, (qw.float() - zw) * sw, b, st, pd)
+            xin = qx if sx is None else (qx.float() - zx) * sx          # float-input operator: activations as they are
+            F.conv2d(xin, (qw.float() - zw) * sw, b, st, pd)
     with torch.no_grad():
         run()                      # warm-up: oneDNN primitive creation
         t0 = time.perf_counter()
@@ -166,6 +196,19 @@ def cpu_baseline(layers, args, torch):
     oracle.set_num_threads(avail)
     threads = oracle.num_threads()
     work = []
+    if layers and layers[0].float_input:
+        for L in layers:
+            sp = L.spec
+            wd = np.array([args.w_bits, 1, sp.OC, sp.IC, sp.K, sp.K], np.int32)
+            work.append((L.xf[:n_img].cpu().numpy(), L.wp.cpu().numpy(), wd, L.sw.cpu().numpy(), L.zw.cpu().numpy(),
+                         None if L.bias is None else L.bias.cpu().numpy(), sp.stride, sp.pad))
+        t0 = time.perf_counter()
+        for w in work:
+            oracle.quantconv2d_float_input(*w, mode="fp32")
+        dt = time.perf_counter() - t0
+        return {"value": n_img / dt, "unit": "images/s", "cores": threads, "threads": threads, "kind": "port",
+                "sample": "%d images through all %d conv layers (oracle/qe_oracle.c float-input loop, OpenMP over outputs), %.1f s"
+                          % (n_img, len(layers), dt)}
     for L in layers:
         sp = L.spec
         per_img = sp.IC * sp.H * sp.H * args.a_bits // 8
@@ -335,7 +378,7 @@ def main():
         traffic, traffic_tag = None, None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath) and not args.layers and N == 256 and args.w_bits == 8 and args.a_bits == 8 \
-                and not args.asymmetric:
+                and not args.asymmetric and not args.float_input:
             try:
                 from quantize_amd.build import source_sha16
                 tj = json.load(open(tpath))
@@ -344,7 +387,8 @@ def main():
             except Exception:
                 traffic = None
         result = {
-            "metric": "quant-conv2d images/sec at batch 256 (ResNet-50, W%dA%d)" % (args.w_bits, args.a_bits),
+            "metric": ("quant-conv2d images/sec at batch 256 (ResNet-50, W%dA%d)" % (args.w_bits, args.a_bits)) if not args.float_input
+                      else "quantconv2d_float_input images/sec at batch 256 (ResNet-50, W%d, fp32 activations)" % args.w_bits,
             "value": N * world * args.steps / elapsed,
             "unit": "images/s",
             "n_gpus": world,
@@ -354,10 +398,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int8" if (args.w_bits <= 8 and args.a_bits <= 8) else "f32",
+            "dtype": "bf16x3 (exact split of f32) x int codes, f32 accumulate" if args.float_input else "int8",
             "data": "synthetic",
-            "config": {"workload": "ResNet-50 conv stack (53 convs), W%dA%d packed-int quantconv2d, "
-                                   "NCHW (256,3,224,224) per GPU, fp32 NCHW outputs" % (args.w_bits, args.a_bits),
+            "config": {"workload": ("ResNet-50 conv stack (53 convs), W%dA%d packed-int quantconv2d, "
+                                    "NCHW (256,3,224,224) per GPU, fp32 NCHW outputs" % (args.w_bits, args.a_bits)) if not args.float_input
+                                   else "ResNet-50 conv stack (53 convs), quantconv2d_float_input: fp32 NCHW activations x packed W%d weights, "
+                                        "fp32 NCHW outputs" % args.w_bits,
                        "batch_per_gpu": N, "global_batch": N * world,
                        "parallelism": "batch-sharded x%d, all-gather of logits" % world,
                        "launch": launch_mode,
@@ -366,7 +412,11 @@ def main():
                        "layers": n_launch, "kernel_paths": {"mfma": sum(L.path for L in layers),
                                                             "generic": sum(1 - L.path for L in layers)}},
             "roofline": {"bound": "hbm",
-                         "kernel": "conv_mfma_{flat,sm2,ws,smallic,}_kernel: flat/flatg/sm2/halo/ws/stem, 53 launches per step, one per layer (the event span also holds the 15 weight-prep and 2 gather launches, 3 us per layer)",
+                         "kernel": ("conv_f32_mfma_kernel (bf16 x3 MFMA; the 3-channel stem on conv_generic_kernel), 53 launches per step, one per layer"
+                                    if args.float_input else
+                                    "conv_mfma_{flat,flatg,sm2,ws,smallic,}_kernel + conv_flatd_kernel: one launch per layer, 53 per step (the event span "
+                                    "also holds the 2 gather launches of the strided 1x1 layers%s)"
+                                    % (" and the 17 weight-prep launches" if args.per_call_prepare else "; weights prepared at set-up")),
                          "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": traffic,

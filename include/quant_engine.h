@@ -179,6 +179,26 @@ int qe_quantconv2d_prepared(const qe_qparam *x, const qe_qparam *w, const float 
 int qe_quantconv2d_float_input(const float *x, const qe_qparam *w, const float *bias,
                                const qe_conv_shape *shape, float *out, qe_stream_t stream);
 
+/* The same operator on the matrix cores (exact 3-way bf16 split of the fp32 activations x integer weight codes,
+ * fp32 accumulation; quantize_amd/csrc/qe_conv_f32.hip).  It needs scratch for the weights in fragment order, which
+ * the reference's signature has no place for, hence the _ws form; the plain entry point above keeps the
+ * order-preserving VALU kernel (bit-identical to the reference's fmaf chain).  Results of the two differ by fp32
+ * accumulation order only (within max(1e-5, |reference chain - exact|), tests/test_conv_f32_gpu.py).
+ * qe_quantconv2d_float_input_workspace_bytes() == 0 or path == 0: the problem stays on the VALU kernel.
+ * The weight tables are x-independent: qe_conv_f32_prepare once + qe_quantconv2d_float_input_prepared per call keeps
+ * them across forward passes (same contract as qe_conv_prepare). */
+size_t qe_quantconv2d_float_input_workspace_bytes(const qe_conv_shape *shape, int w_bits);
+int qe_quantconv2d_float_input_ws(const float *x, const qe_qparam *w, const float *bias,
+                                  const qe_conv_shape *shape, float *out, void *workspace,
+                                  size_t workspace_bytes, qe_stream_t stream);
+int qe_conv_f32_prepare(const qe_qparam *w, const float *bias, const qe_conv_shape *shape,
+                        void *prepared, size_t prepared_bytes, qe_stream_t stream);
+int qe_quantconv2d_float_input_prepared(const float *x, const qe_qparam *w, const float *bias,
+                                        const qe_conv_shape *shape, const void *prepared,
+                                        size_t prepared_bytes, float *out, qe_stream_t stream);
+/* 0 = order-preserving VALU kernel, 1 = bf16 MFMA kernel */
+int qe_quantconv2d_float_input_path(const qe_conv_shape *shape, const qe_qparam *w);
+
 /* Which kernel family qe_quantconv2d will pick for a problem (for tests, bench
  * and profiles): 0 = generic fp32 direct convolution, 1 = int8 MFMA implicit GEMM. */
 int qe_quantconv2d_path(const qe_conv_shape *shape, const qe_qparam *x, const qe_qparam *w);

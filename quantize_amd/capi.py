@@ -20,7 +20,9 @@ SYMBOLS = ["qe_error_string", "qe_last_hip_error", "qe_version", "qe_target_arch
            "qe_tpack", "qe_tunpack", "qe_quantconv2d_workspace_bytes", "qe_quantconv2d",
            "qe_quantconv2d_float_input", "qe_quantconv2d_path", "qe_quantlinear", "qe_quantlinear_float_input",
            "qe_quantlinear_path", "qe_global_avgpool", "qe_conv_prepared_bytes", "qe_quantconv2d_prepared_workspace_bytes",
-           "qe_conv_prepare", "qe_quantconv2d_prepared", "qe_quantize_pack"]
+           "qe_conv_prepare", "qe_quantconv2d_prepared", "qe_quantize_pack", "qe_quantconv2d_float_input_workspace_bytes",
+           "qe_quantconv2d_float_input_ws", "qe_conv_f32_prepare", "qe_quantconv2d_float_input_prepared",
+           "qe_quantconv2d_float_input_path"]
 
 
 class QeConvShape(ctypes.Structure):
@@ -83,6 +85,16 @@ def lib():
     L.qe_quantconv2d_prepared.restype = i32
     L.qe_quantconv2d_prepared.argtypes = [ctypes.POINTER(QeQParam), ctypes.POINTER(QeQParam), vp, ctypes.POINTER(QeConvShape),
                                           vp, sz, vp, vp, sz, vp]
+    L.qe_quantconv2d_float_input_workspace_bytes.restype = sz
+    L.qe_quantconv2d_float_input_workspace_bytes.argtypes = [ctypes.POINTER(QeConvShape), i32]
+    L.qe_quantconv2d_float_input_ws.restype = i32
+    L.qe_quantconv2d_float_input_ws.argtypes = [vp, ctypes.POINTER(QeQParam), vp, ctypes.POINTER(QeConvShape), vp, vp, sz, vp]
+    L.qe_conv_f32_prepare.restype = i32
+    L.qe_conv_f32_prepare.argtypes = [ctypes.POINTER(QeQParam), vp, ctypes.POINTER(QeConvShape), vp, sz, vp]
+    L.qe_quantconv2d_float_input_prepared.restype = i32
+    L.qe_quantconv2d_float_input_prepared.argtypes = [vp, ctypes.POINTER(QeQParam), vp, ctypes.POINTER(QeConvShape), vp, sz, vp, vp]
+    L.qe_quantconv2d_float_input_path.restype = i32
+    L.qe_quantconv2d_float_input_path.argtypes = [ctypes.POINTER(QeConvShape), ctypes.POINTER(QeQParam)]
     L.qe_quantize_pack.restype = i32
     L.qe_quantize_pack.argtypes = [vp, i64, vp, vp, i32, i64, ctypes.c_float, ctypes.c_float, i32, i32, vp, vp, vp]
     _lib = L
@@ -216,15 +228,45 @@ def quantize_pack(x, scale, zero, qmin, qmax, n_bits, sign, inner=1, out=None, s
     return out, status
 
 
-def quantconv2d_float_input(x, wq, bias, sh, out=None, stream=None):
+def quantconv2d_float_input(x, wq, bias, sh, out=None, stream=None, mfma=True):
+    """mfma=True: qe_quantconv2d_float_input_ws (bf16 MFMA kernel where eligible); False: the order-preserving VALU kernel."""
     import torch
     assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32
     OH, OW = out_hw(sh)
     if out is None:
         out = torch.empty((sh.N, sh.OC, OH, OW), dtype=torch.float32, device=x.device)
-    check(lib().qe_quantconv2d_float_input(x.data_ptr(), ctypes.byref(wq),
-                                           None if bias is None else bias.data_ptr(), ctypes.byref(sh),
-                                           out.data_ptr(), _stream(stream)))
+    bp = None if bias is None else bias.data_ptr()
+    if mfma:
+        need = int(lib().qe_quantconv2d_float_input_workspace_bytes(ctypes.byref(sh), wq.n_bits))
+        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
+        check(lib().qe_quantconv2d_float_input_ws(x.data_ptr(), ctypes.byref(wq), bp, ctypes.byref(sh), out.data_ptr(),
+                                                  ws.data_ptr(), ws.numel(), _stream(stream)))
+    else:
+        check(lib().qe_quantconv2d_float_input(x.data_ptr(), ctypes.byref(wq), bp, ctypes.byref(sh), out.data_ptr(), _stream(stream)))
+    return out
+
+
+def float_input_path(sh, wq):
+    return int(lib().qe_quantconv2d_float_input_path(ctypes.byref(sh), ctypes.byref(wq)))
+
+
+def conv_f32_prepare(wq, bias, sh, stream=None):
+    import torch
+    need = int(lib().qe_quantconv2d_float_input_workspace_bytes(ctypes.byref(sh), wq.n_bits))
+    prepared = torch.empty(need, dtype=torch.uint8, device=wq._keep[0].device)
+    check(lib().qe_conv_f32_prepare(ctypes.byref(wq), None if bias is None else bias.data_ptr(), ctypes.byref(sh),
+                                    prepared.data_ptr() if need else None, need, _stream(stream)))
+    return prepared
+
+
+def quantconv2d_float_input_prepared(x, wq, bias, sh, prepared, out=None, stream=None):
+    import torch
+    OH, OW = out_hw(sh)
+    if out is None:
+        out = torch.empty((sh.N, sh.OC, OH, OW), dtype=torch.float32, device=x.device)
+    check(lib().qe_quantconv2d_float_input_prepared(x.data_ptr(), ctypes.byref(wq), None if bias is None else bias.data_ptr(),
+                                                    ctypes.byref(sh), prepared.data_ptr() if prepared.numel() else None,
+                                                    prepared.numel(), out.data_ptr(), _stream(stream)))
     return out
 
 

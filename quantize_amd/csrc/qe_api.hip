@@ -17,6 +17,12 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
                      float *out, void *workspace, size_t workspace_bytes, hipStream_t s, int mode, void *prepared,
                      size_t prepared_bytes);
 
+// qe_conv_f32.hip
+bool f32_conv_eligible(const qe_conv_shape *sh, const qe_qparam *w);
+size_t f32_conv_prepared_bytes(const qe_conv_shape *sh);
+int launch_conv_f32(const float *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh, float *out,
+                    void *prepared, size_t prepared_bytes, hipStream_t s, int mode);
+
 static int check_shape(const qe_conv_shape *sh)
 {
     if (sh == nullptr) return QE_ERR_ARG;
@@ -134,6 +140,59 @@ extern "C" int qe_quantconv2d_float_input(const float *x, const qe_qparam *w, co
     if ((rc = check_qparam(w)) != QE_OK) return rc;
     if (x == nullptr || out == nullptr) return QE_ERR_ARG;
     return launch_conv_generic(false, x, nullptr, w, bias, shape, out, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int qe_quantconv2d_float_input_path(const qe_conv_shape *shape, const qe_qparam *w)
+{
+    if (qe::check_shape(shape) != QE_OK || w == nullptr) return 0;
+    return qe::f32_conv_eligible(shape, w) ? 1 : 0;
+}
+
+extern "C" size_t qe_quantconv2d_float_input_workspace_bytes(const qe_conv_shape *shape, int w_bits)
+{
+    (void)w_bits;
+    if (qe::check_shape(shape) != QE_OK) return 0;
+    return qe::f32_conv_prepared_bytes(shape);
+}
+
+extern "C" int qe_quantconv2d_float_input_ws(const float *x, const qe_qparam *w, const float *bias,
+                                             const qe_conv_shape *shape, float *out, void *workspace,
+                                             size_t workspace_bytes, qe_stream_t stream)
+{
+    using namespace qe;
+    int rc = check_shape(shape);
+    if (rc != QE_OK) return rc;
+    if ((rc = check_qparam(w)) != QE_OK) return rc;
+    if (x == nullptr || out == nullptr) return QE_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (f32_conv_eligible(shape, w)) return launch_conv_f32(x, w, bias, shape, out, workspace, workspace_bytes, s, 0);
+    return launch_conv_generic(false, x, nullptr, w, bias, shape, out, s);
+}
+
+extern "C" int qe_conv_f32_prepare(const qe_qparam *w, const float *bias, const qe_conv_shape *shape,
+                                   void *prepared, size_t prepared_bytes, qe_stream_t stream)
+{
+    using namespace qe;
+    int rc = check_shape(shape);
+    if (rc != QE_OK) return rc;
+    if ((rc = check_qparam(w)) != QE_OK) return rc;
+    if (!f32_conv_eligible(shape, w)) return QE_OK;          // nothing to prepare: the VALU kernel reads the packed weights
+    return launch_conv_f32(nullptr, w, bias, shape, nullptr, prepared, prepared_bytes, static_cast<hipStream_t>(stream), 1);
+}
+
+extern "C" int qe_quantconv2d_float_input_prepared(const float *x, const qe_qparam *w, const float *bias,
+                                                   const qe_conv_shape *shape, const void *prepared,
+                                                   size_t prepared_bytes, float *out, qe_stream_t stream)
+{
+    using namespace qe;
+    int rc = check_shape(shape);
+    if (rc != QE_OK) return rc;
+    if ((rc = check_qparam(w)) != QE_OK) return rc;
+    if (x == nullptr || out == nullptr) return QE_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (f32_conv_eligible(shape, w))
+        return launch_conv_f32(x, w, bias, shape, out, const_cast<void *>(prepared), prepared_bytes, s, 2);
+    return launch_conv_generic(false, x, nullptr, w, bias, shape, out, s);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -523,6 +523,48 @@ torch::Tensor quantconv2d_float_input(const torch::Tensor &input, const torch::T
     c10::hip::HIPGuardMasqueradingAsCUDA guard(input.device());
     auto output = torch::empty({sh.N, sh.OC, OH, OW}, input.options());
     const qe_qparam wq = make_qparam(weight, wd, weight_scale, weight_zero);
+    // bf16 MFMA kernel where the problem is eligible (its weight tables are x-independent: cached like the packed
+    // operator's), the order-preserving VALU kernel otherwise
+    const size_t prep_bytes = qe_quantconv2d_float_input_path(&sh, &wq) == 1 ? qe_quantconv2d_float_input_workspace_bytes(&sh, wd.n_bits) : 0;
+    if (prep_bytes > 0) {
+        const bool use_cache = cacheable(weight) && cacheable(weight_scale) && cacheable(weight_zero) &&
+                               (!bias.has_value() || cacheable(bias.value()));
+        torch::Tensor prepared;
+        if (use_cache) {
+            std::lock_guard<std::mutex> lock(g_cache_mutex);
+            auto it = g_prep_cache.find(weight.unsafeGetTensorImpl());
+            if (it != g_prep_cache.end()) {
+                const PrepEntry &e = it->second;
+                const bool hit = e.w.matches(weight) && e.s.matches(weight_scale) && e.z.matches(weight_zero) &&
+                                 e.has_bias == bias.has_value() && (!e.has_bias || e.b.matches(bias.value())) &&
+                                 e.x_bits == 32 && e.w_bits == wd.n_bits && e.w_sign == wd.sign &&
+                                 std::memcmp(&e.sh, &sh, sizeof(sh)) == 0 && (size_t)e.prepared.numel() == prep_bytes &&
+                                 e.stream == current_stream(input);
+                if (hit) { prepared = e.prepared; ++g_prep_hits; }
+            }
+        }
+        if (!prepared.defined()) {
+            prepared = torch::empty({(int64_t)prep_bytes}, torch::dtype(torch::kByte).device(input.device()));
+            check_status(qe_conv_f32_prepare(&wq, bias_ptr, &sh, prepared.data_ptr(), prep_bytes, current_stream(input)),
+                         "quantconv2d_float_input (prepare)");
+            if (use_cache) {
+                PrepEntry e;
+                e.w = TensorKey::of(weight); e.s = TensorKey::of(weight_scale); e.z = TensorKey::of(weight_zero);
+                e.has_bias = bias.has_value();
+                if (e.has_bias) e.b = TensorKey::of(bias.value());
+                e.x_bits = 32; e.w_bits = wd.n_bits; e.w_sign = wd.sign; e.sh = sh; e.prepared = prepared;
+                e.stream = current_stream(input);
+                std::lock_guard<std::mutex> lock(g_cache_mutex);
+                ++g_prep_misses;
+                if (g_prep_cache.size() > 4096) g_prep_cache.clear();
+                g_prep_cache[weight.unsafeGetTensorImpl()] = e;
+            }
+        }
+        check_status(qe_quantconv2d_float_input_prepared(input.data_ptr<float>(), &wq, bias_ptr, &sh, prepared.data_ptr(), prep_bytes,
+                                                         output.data_ptr<float>(), current_stream(input)),
+                     "quantconv2d_float_input");
+        return output;
+    }
     check_status(qe_quantconv2d_float_input(input.data_ptr<float>(), &wq, bias_ptr, &sh, output.data_ptr<float>(),
                                             current_stream(input)),
                  "quantconv2d_float_input");

@@ -1,0 +1,106 @@
+"""GPU: quantconv2d_float_input on the bf16 MFMA kernel (qe_conv_f32.hip: exact 3-way bf16 split of the fp32 activations
+x integer weight codes) vs the oracle.  Bar: |out - exact64| <= max(1e-5, |reference fp32 chain - exact64|) (the
+reference's own sequential chain, as written and contracted), and plain 1e-5 on the ResNet-50 layer shapes at the
+headline weight scales.  The order-preserving VALU kernel stays bit-identical to the contracted chain."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import conv_tolerance
+from quantize_amd import capi, resnet50
+from test_conv_gpu import _random_case, _run_case, _assert_conv_close, _t, engine  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    # N, IC, H, W, OC, K, stride, pad
+    (2, 64, 56, 56, 64, 3, 1, 1),
+    (2, 64, 28, 28, 130, 3, 1, 1),      # ragged output-channel tile
+    (3, 128, 14, 14, 256, 3, 1, 1),
+    (5, 160, 7, 7, 96, 3, 1, 1),        # several images per tile, last group partial, padded last channel group
+    (2, 96, 30, 30, 72, 3, 2, 1),       # stride 2
+    (2, 64, 56, 56, 256, 1, 1, 0),
+    (2, 256, 56, 56, 64, 1, 1, 0),
+    (3, 72, 28, 28, 40, 1, 2, 0),       # strided 1x1 (sampled rows / columns only), IC % 16 != 0
+    (2, 40, 17, 19, 24, 5, 1, 2),       # 5x5, odd plane, quads crossing the row end
+    (1, 16, 9, 9, 8, 3, 1, 0),          # no padding
+    (9, 512, 7, 7, 128, 1, 1, 0),
+    (2, 8, 12, 12, 16, 3, 1, 1),        # the smallest eligible channel depth
+]
+
+
+def test_float_input_mfma_vs_oracle(engine):
+    rng = np.random.RandomState(321)
+    n_mfma = 0
+    for shp in SHAPES:
+        for (wb, wsgn, zeros) in [(8, 1, False), (8, 0, True), (4, 1, True), (3, 0, False)]:
+            for via_capi in (False, True):
+                case = _random_case(rng, *shp, wb, wsgn, 0, 0, w_pc=True, a_pc=False, zeros=zeros, bias=True)
+                y, o32, o64 = _run_case(engine, case, via_capi=via_capi)
+                n_mfma += int(case["path"] == 2)
+                _assert_conv_close(y, o64, o32, "f32 %s w%d sgn%d zeros=%s capi=%s" % (shp, wb, wsgn, zeros, via_capi), case["fma"])
+    assert n_mfma >= 80
+
+
+def test_resnet50_shapes_1e5():
+    """All 22 non-stem ResNet-50 conv shapes (the stem's 3 input channels stay on the VALU kernel), N = 1, headline
+    weight scales, fp32 activations ~ N(0, 0.25): plain 1e-5 absolute against the float64-exact value."""
+    rng = np.random.RandomState(8)
+    seen = set()
+    for layer in resnet50.conv_layers():
+        sig = tuple(layer[1:])
+        if sig in seen or layer.IC < 8:
+            continue
+        seen.add(sig)
+        qw = rng.randint(-128, 128, size=(layer.OC, layer.IC, layer.K, layer.K))
+        sw = rng.uniform(2.5e-4, 7.5e-4, size=layer.OC).astype(np.float32)
+        zw = np.zeros(layer.OC, np.float32)
+        bias = rng.normal(0, 0.1, size=layer.OC).astype(np.float32)
+        xf = rng.normal(0, 0.5, size=(1, layer.IC, layer.H, layer.H)).astype(np.float32)
+        wp, wd = oracle.tpack(qw, 8, True)
+        sh = capi.conv_shape(1, layer.IC, layer.H, layer.H, layer.OC, layer.K, layer.K, layer.stride, layer.pad)
+        wq = capi.qparam(_t(wp), 8, 1, _t(sw), _t(zw))
+        assert capi.float_input_path(sh, wq) == 1, layer.name
+        y = capi.quantconv2d_float_input(_t(xf), wq, _t(bias), sh).cpu().numpy()
+        _, o64 = oracle.quantconv2d_float_input(xf, wp, wd, sw, zw, bias, layer.stride, layer.pad, mode="f64", return_f64=True)
+        assert np.abs(y.astype(np.float64) - o64).max() <= 1e-5, layer.name
+    assert len(seen) == 22
+
+
+def test_prepared_and_valu_forms():
+    rng = np.random.RandomState(12)
+    for shp in [(2, 64, 28, 28, 96, 3, 1, 1), (3, 128, 14, 14, 64, 1, 1, 0)]:
+        case = _random_case(rng, *shp, 8, 1, 0, 0, w_pc=True, a_pc=False, zeros=True, bias=True)
+        wp, wd, sw, zw = case["w"]
+        xf = _t(case["xf"])
+        N, IC, H, W = case["xf"].shape
+        sh = capi.conv_shape(N, IC, H, W, int(wd[2]), int(wd[4]), int(wd[5]), case["stride"], case["pad"])
+        wq = capi.qparam(_t(wp), int(wd[0]), int(wd[1]), _t(sw), _t(zw))
+        bias = _t(case["bias"])
+        y0 = capi.quantconv2d_float_input(xf, wq, bias, sh)                      # prepare + run
+        prepared = capi.conv_f32_prepare(wq, bias, sh)
+        assert prepared.numel() > 0
+        y1 = capi.quantconv2d_float_input_prepared(xf, wq, bias, sh, prepared)  # run on kept tables
+        assert torch.equal(y0, y1)
+        # the plain entry point keeps the order-preserving kernel: bit-identical to the reference's contracted chain
+        yv = capi.quantconv2d_float_input(xf, wq, bias, sh, mfma=False).cpu().numpy()
+        fma = oracle.quantconv2d_float_input(case["xf"], wp, wd, sw, zw, case["bias"], case["stride"], case["pad"], mode="fp32_fma")
+        assert np.array_equal(yv, fma)
+
+
+def test_env_switch_keeps_valu_kernel(engine):
+    rng = np.random.RandomState(13)
+    old = os.environ.get("QE_F32_MFMA")
+    os.environ["QE_F32_MFMA"] = "0"
+    try:
+        case = _random_case(rng, 2, 64, 14, 14, 48, 3, 1, 1, 8, 1, 0, 0, w_pc=True, a_pc=False, zeros=True, bias=True)
+        y, o32, o64 = _run_case(engine, case, via_capi=False)
+        assert case["path"] == 0 and np.array_equal(y, case["fma"])
+    finally:
+        if old is None:
+            os.environ.pop("QE_F32_MFMA", None)
+        else:
+            os.environ["QE_F32_MFMA"] = old

@@ -36,7 +36,7 @@ def _shapes(rng, n):
 def test_fuzz_vs_oracle(engine, seed):
     rng = np.random.RandomState(seed)
     quant = [(8, 1, 8, 1), (8, 0, 8, 0), (8, 1, 8, 0), (4, 1, 4, 1), (8, 1, 4, 0), (5, 0, 7, 1), (2, 1, 8, 1), (8, 1, 0, 0)]
-    paths = {0: 0, 1: 0}
+    paths = {0: 0, 1: 0, 2: 0}
     for k, shp in enumerate(_shapes(rng, 60)):
         wb, wsgn, ab, asgn = quant[rng.randint(len(quant))]
         case = _random_case(rng, *shp, wb, wsgn, ab, asgn, w_pc=bool(rng.randint(2)), a_pc=(ab != 0 and rng.randint(8) == 0),

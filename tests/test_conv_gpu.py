@@ -138,7 +138,10 @@ def _run_case(engine, case, via_capi=False):
         else:
             y = engine.quantconv2d_float_input(_t(xf), *w, bias, case["stride"], case["pad"])
         o32 = oracle.quantconv2d_float_input(xf, wp, wd, sw, zw, case["bias"], case["stride"], case["pad"], mode="fp32")
-        case["path"] = 0
+        # 0: order-preserving VALU kernel (bit-identical to the fmaf chain), 2: bf16 MFMA kernel (tolerance rule)
+        N, IC, H, W = xf.shape
+        sh = capi.conv_shape(N, IC, H, W, int(wd[2]), int(wd[4]), int(wd[5]), case["stride"], case["pad"])
+        case["path"] = 2 if capi.float_input_path(sh, capi.qparam(w[0], int(wd[0]), int(wd[1]), w[2], w[3])) else 0
         case["fma"] = oracle.quantconv2d_float_input(xf, wp, wd, sw, zw, case["bias"], case["stride"], case["pad"],
                                                      mode="fp32_fma")
         _, o64 = oracle.quantconv2d_float_input(xf, wp, wd, sw, zw, case["bias"], case["stride"], case["pad"],
