@@ -107,7 +107,9 @@ __global__ __launch_bounds__(256) void conv_f32_prep_kernel(const F32PrepArgs a)
     }
 }
 
-template <int WM, int WN, int NIW>
+// NS = 16-channel groups per stage: 2 where 4 x (units per k-half) <= 256 threads and the LDS allows (every 1x1 layer:
+// a 224-pixel tile is 56 row-quads): half the stages, i.e. half the exposed memory round trips of the K loop.
+template <int WM, int WN, int NIW, int NS>
 __global__ __launch_bounds__(F32_THREADS, 2) void conv_f32_mfma_kernel(const F32Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -137,11 +139,11 @@ __global__ __launch_bounds__(F32_THREADS, 2) void conv_f32_mfma_kernel(const F32
     const int ih0 = oh0 * a.stride - a.pad;
     const int ISZ = a.IHT * a.IWP, GSZ = a.GI * ISZ;
     const int KK = a.KH * a.KW;
-    const int trash = 6 * GSZ + lane;
-    float *sxp = reinterpret_cast<float *>(Xs + 6 * GSZ + F32_TRASH);      // [GSZ] per-input-pixel channel sums
+    const int trash = 6 * NS * GSZ + lane;
+    float *sxp = reinterpret_cast<float *>(Xs + 6 * NS * GSZ + F32_TRASH);      // [2 NS][GSZ] per-input-pixel channel sums of each staging slice
 
-    for (int i = tid; i < 6 * GSZ; i += F32_THREADS) Xs[i] = make_uint4(0, 0, 0, 0);
-    for (int i = tid; i < GSZ; i += F32_THREADS) sxp[i] = 0.0f;
+    for (int i = tid; i < 6 * NS * GSZ; i += F32_THREADS) Xs[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < 2 * NS * GSZ; i += F32_THREADS) sxp[i] = 0.0f;
 
     // ---- per-lane pixel bases of the wave's column tiles (uint4 index; split s adds 2 s GSZ) -------------------
     const int RS = a.stride / a.ROWMUL, CS = a.stride / a.COLMUL;
@@ -159,16 +161,18 @@ __global__ __launch_bounds__(F32_THREADS, 2) void conv_f32_mfma_kernel(const F32
     const int NQ = (a.W + 3) >> 2;
     const int U = a.GI * a.IHT * NQ;                 // units per k-half (host: 2 U <= 256)
     const int HW = a.H * a.W;
-    const int hh = tid >= U ? 1 : 0;
+    const int sub = (NS == 2 && tid >= 2 * U) ? 1 : 0;          // which group of the stage this thread stages
+    const int tsub = tid - sub * 2 * U;
+    const int hh = tsub >= U ? 1 : 0;
     int u_off = 0, u_es = 0, u_lds[4];
     bool u_live;
     {
-        const int lt = tid - hh * U;
+        const int lt = tsub - hh * U;
         const int gi = lt / (a.IHT * NQ);
         const int rr = lt - gi * (a.IHT * NQ);
         const int l = rr / NQ, iq = rr - l * NQ;
         const int ih = ih0 + l * a.ROWMUL;
-        u_live = lt < U && tid < 2 * U;
+        u_live = lt < U && tsub < 2 * U;
         const bool ok = u_live && gi < a.GI && n0 + gi < a.N && ih >= 0 && ih < a.H;
         int iw0 = 4 * iq;
         if (iw0 + 4 > a.W) { u_es = iw0 + 4 - a.W; iw0 = a.W - 4; }       // never read past the row (W >= 4): shifted back
@@ -202,7 +206,8 @@ __global__ __launch_bounds__(F32_THREADS, 2) void conv_f32_mfma_kernel(const F32
 
     float4 d[8];
     float sx_priv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    auto issue_x = [&](int g) __attribute__((always_inline)) {
+    auto issue_x = [&](int st) __attribute__((always_inline)) {
+        const int g = st * NS + sub;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int ic = g * 16 + hh * 8 + i;
@@ -210,7 +215,8 @@ __global__ __launch_bounds__(F32_THREADS, 2) void conv_f32_mfma_kernel(const F32
             __builtin_memcpy(&d[i], xi + ((int64_t)icc * HW + u_off), 16);     // 4-byte aligned global_load_dwordx4
         }
     };
-    auto stage_x = [&](int g) __attribute__((always_inline)) {
+    auto stage_x = [&](int st) __attribute__((always_inline)) {
+        const int g = st * NS + sub;
         // pixel j of the quad sits at element j + u_es of the (shifted-back) load: rotate once per channel
         float xr[8][4];
 #pragma unroll
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(F32_THREADS, 2) void conv_f32_mfma_kernel(const F32
             }
             if (need_sx) sx_priv[j] += s;
             const bool live = u_lds[j] >= 0;
-            const int idx = live ? u_lds[j] + hh * GSZ : trash;
+            const int idx = live ? u_lds[j] + (sub * 6 + hh) * GSZ : trash;
             // one split at a time: the truncated part goes to LDS (8 channels x bf16 = one 16-byte vector: dword m holds
             // channels 2m (low half) and 2m + 1 (high half)), the exact remainder stays in x
 #pragma unroll
@@ -251,29 +257,35 @@ __global__ __launch_bounds__(F32_THREADS, 2) void conv_f32_mfma_kernel(const F32
         }
     };
 
-    const int n_groups = a.NG;
+    const int n_stages = a.NG / NS;             // NG is padded to a multiple of NS by the host (zero weights)
     issue_x(0);
-    for (int g = 0; g < n_groups; ++g) {
-        const uint16_t *a_g = a_base + (int64_t)g * grp_stride;
-        v4i af = *reinterpret_cast<const v4i *>(a_g);                        // tap 0, requested before the staging work
-        stage_x(g);
+    for (int st = 0; st < n_stages; ++st) {
+        const uint16_t *a_g = a_base + (int64_t)(st * NS) * grp_stride;
+        v4i af = *reinterpret_cast<const v4i *>(a_g);                        // group 0 / tap 0, requested before the staging work
+        stage_x(st);
         __syncthreads();
-        if (g + 1 < n_groups) issue_x(g + 1);
-        for (int tap = 0; tap < KK; ++tap) {
-            const int nxt = tap + 1 < KK ? tap + 1 : tap;
-            const v4i af_next = *reinterpret_cast<const v4i *>(a_g + (int64_t)nxt * tap_stride);
-            const int kh = tap / a.KW;
-            const int off = kh * a.IWP + (tap - kh * a.KW);
-            const v8bf wf = __builtin_bit_cast(v8bf, af);
+        if (st + 1 < n_stages) issue_x(st + 1);
 #pragma unroll
-            for (int t = 0; t < NIW; ++t) {
+        for (int k = 0; k < NS; ++k) {
+            for (int tap = 0; tap < KK; ++tap) {
+                // next fragment: next tap of this group, or tap 0 of the stage's second group
+                const bool last_tap = tap + 1 == KK;
+                const uint16_t *nx = (last_tap && k + 1 < NS) ? a_g + (int64_t)(k + 1) * grp_stride
+                                                                : a_g + (int64_t)k * grp_stride + (int64_t)(last_tap ? tap : tap + 1) * tap_stride;
+                const v4i af_next = *reinterpret_cast<const v4i *>(nx);
+                const int kh = tap / a.KW;
+                const int off = k * 6 * GSZ + kh * a.IWP + (tap - kh * a.KW);
+                const v8bf wf = __builtin_bit_cast(v8bf, af);
 #pragma unroll
-                for (int s = 2; s >= 0; --s) {                                   // smallest parts first
-                    const v4i b = *reinterpret_cast<const v4i *>(&Xs[pixidx[t] + off + 2 * s * GSZ]);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(v8bf, b), acc[t], 0, 0, 0);
+                for (int t = 0; t < NIW; ++t) {
+#pragma unroll
+                    for (int sp = 2; sp >= 0; --sp) {                            // smallest parts first
+                        const v4i b = *reinterpret_cast<const v4i *>(&Xs[pixidx[t] + off + 2 * sp * GSZ]);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(v8bf, b), acc[t], 0, 0, 0);
+                    }
                 }
+                af = af_next;
             }
-            af = af_next;
         }
         __syncthreads();
     }
@@ -283,17 +295,21 @@ __global__ __launch_bounds__(F32_THREADS, 2) void conv_f32_mfma_kernel(const F32
 #pragma unroll
     for (int t = 0; t < NIW; ++t) sxs[t] = 0.0f;
     if (need_sx) {
-        // the two k-halves of a pixel add their private sums (two addends: order-independent), then one barrier
+        // every staging thread owns one (group-of-the-stage, k-half) slice of its pixels: private slots, summed in a
+        // fixed order (no atomics: the result does not depend on the order the threads arrive in)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (u_lds[j] >= 0) atomicAdd(&sxp[u_lds[j]], sx_priv[j]);
+            if (u_lds[j] >= 0) sxp[(sub * 2 + hh) * GSZ + u_lds[j]] = sx_priv[j];
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < NIW; ++t) {
             const int pbase = pixidx[t] - h * GSZ;
             for (int tap = 0; tap < KK; ++tap) {
                 const int kh = tap / a.KW;
-                sxs[t] += sxp[pbase + kh * a.IWP + (tap - kh * a.KW)];         // zero outside the image
+                const int o = pbase + kh * a.IWP + (tap - kh * a.KW);           // zero outside the image
+                float v = sxp[o] + sxp[GSZ + o];
+                if constexpr (NS == 2) v += sxp[2 * GSZ + o] + sxp[3 * GSZ + o];
+                sxs[t] += v;
             }
         }
     }
@@ -336,7 +352,7 @@ struct F32Plan {
     bool ok = false;
     int cfg = 0;               // 0: 4x1 waves x 7 column tiles (MT 128), 1: 2x2 x 4 (MT 64)
     int MT = 0, OCP = 0, NG = 0, KK = 0, OH = 0, OW = 0;
-    int TH = 0, GI = 1, IHT = 0, IWP = 0, ROWMUL = 1, COLMUL = 1;
+    int TH = 0, GI = 1, IHT = 0, IWP = 0, ROWMUL = 1, COLMUL = 1, NS = 1;
     size_t lds = 0, wt_bytes = 0, ep_off = 0, total = 0;
 };
 
@@ -370,7 +386,7 @@ static F32Plan f32_plan(const qe_conv_shape *sh)
         const int IWP = (p.COLMUL > 1) ? p.OW : (p.OW - 1) * sh->stride + sh->KW;
         const int units = p.GI * IHT * NQ;
         const size_t gsz = (size_t)p.GI * IHT * IWP;
-        const size_t lds = (6 * gsz + F32_TRASH) * 16 + gsz * 4;
+        const size_t lds = (6 * gsz + F32_TRASH) * 16 + 2 * gsz * 4;
         if (lds <= (size_t)F32_MAX_LDS && 2 * units <= F32_THREADS) { p.TH = TH; p.IHT = IHT; p.IWP = IWP; p.lds = lds; break; }
         if (p.GI > 1) { --p.GI; continue; }
         if (--TH < 1) return p;
@@ -382,8 +398,15 @@ static F32Plan f32_plan(const qe_conv_shape *sh)
             p.TH = th2;
             p.IHT = (p.ROWMUL > 1) ? th2 : (th2 - 1) * sh->stride + sh->KH;
             const size_t gsz = (size_t)p.IHT * p.IWP;
-            p.lds = (6 * gsz + F32_TRASH) * 16 + gsz * 4;
+            p.lds = (6 * gsz + F32_TRASH) * 16 + 2 * gsz * 4;
         }
+    }
+    {   // two groups per stage where threads and LDS allow and the K loop is long enough to matter
+        const int units = p.GI * p.IHT * NQ;
+        const size_t gsz = (size_t)p.GI * p.IHT * p.IWP;
+        const size_t lds2 = (12 * gsz + F32_TRASH) * 16 + 4 * gsz * 4;
+        const bool ns2_env = !(getenv("QE_F32_NS") && atoi(getenv("QE_F32_NS")) == 1);
+        if (ns2_env && 4 * units <= F32_THREADS && lds2 <= (size_t)F32_MAX_LDS && p.NG >= 4) { p.NS = 2; p.lds = lds2; p.NG = (p.NG + 1) / 2 * 2; }
     }
     p.wt_bytes = (size_t)p.KK * p.NG * p.OCP * 16 * sizeof(uint16_t);
     if ((int64_t)p.wt_bytes >= (1ll << 31)) return p;
@@ -439,13 +462,17 @@ int launch_conv_f32(const float *x, const qe_qparam *w, const float *bias, const
     const int64_t blocks = (runs + 7) / 8 * a.chunk * 8 * a.n_oc_tiles;
     if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
     const int ni = (p.GI * p.TH * p.OW + 31) / 32;           // column tiles the tile really has
+#define QE_F32_LAUNCH(WM, WN, NIW)                                                                                              \
+    do {                                                                                                                        \
+        if (p.NS == 2) hipLaunchKernelGGL((conv_f32_mfma_kernel<WM, WN, NIW, 2>), dim3((unsigned)blocks), dim3(F32_THREADS), p.lds, s, a); \
+        else hipLaunchKernelGGL((conv_f32_mfma_kernel<WM, WN, NIW, 1>), dim3((unsigned)blocks), dim3(F32_THREADS), p.lds, s, a);           \
+    } while (0)
     if (p.cfg == 0) {
-        if (ni <= 4) hipLaunchKernelGGL((conv_f32_mfma_kernel<4, 1, 4>), dim3((unsigned)blocks), dim3(F32_THREADS), p.lds, s, a);
-        else hipLaunchKernelGGL((conv_f32_mfma_kernel<4, 1, 7>), dim3((unsigned)blocks), dim3(F32_THREADS), p.lds, s, a);
+        if (ni <= 4) QE_F32_LAUNCH(4, 1, 4); else QE_F32_LAUNCH(4, 1, 7);
     } else {
-        if (ni <= 4) hipLaunchKernelGGL((conv_f32_mfma_kernel<2, 2, 2>), dim3((unsigned)blocks), dim3(F32_THREADS), p.lds, s, a);
-        else hipLaunchKernelGGL((conv_f32_mfma_kernel<2, 2, 4>), dim3((unsigned)blocks), dim3(F32_THREADS), p.lds, s, a);
+        if (ni <= 4) QE_F32_LAUNCH(2, 2, 2); else QE_F32_LAUNCH(2, 2, 4);
     }
+#undef QE_F32_LAUNCH
     QE_LAUNCH_CHECK();
     return QE_OK;
 }
