@@ -44,18 +44,18 @@ struct FlatdArgs {
 };
 
 constexpr int FD_CK = 64;              // channels per stage
-constexpr int FD_RING = 3;
+constexpr int FD_RING_DEFAULT = 3;      // slots of the ring (RING - 1 stages in flight); 6 = one workgroup per CU with 5 in flight
 constexpr int FD_MT = 128;             // output channels per workgroup (4 waves x 32)
 constexpr int FD_WBYTES = FD_MT * FD_CK;
 
-template <int NT, bool SMALL> struct FdGeom {
+template <int NT, bool SMALL, int RING = FD_RING_DEFAULT> struct FdGeom {
     static constexpr int RS = SMALL ? 64 : 32 * NT;                  // LDS bytes per channel row (WIDE: NT odd)
     static constexpr int XBYTES = SMALL ? 4 * FD_CK * 64 : FD_CK * RS;
     static constexpr int STAGE = XBYTES + FD_WBYTES;
     static constexpr int XINSTR = XBYTES / 1024;                     // wave-level DMA instructions per stage
     static constexpr int NTP = 32 * NT;
     static constexpr int PATCH = SMALL ? 4 * 32 * 49 * 4 : 4 * 32 * 36 * 4;
-    static constexpr int RING_BYTES = FD_RING * STAGE > PATCH ? FD_RING * STAGE : PATCH;
+    static constexpr int RING_BYTES = RING * STAGE > PATCH ? RING * STAGE : PATCH;
     static constexpr int LDS = RING_BYTES + 4 * NTP * 4 /* S_x, one copy per wave */;
 };
 
@@ -150,10 +150,23 @@ __device__ __forceinline__ void fd_patch_write(uint32_t lds_addr, float a, float
 }
 __device__ __forceinline__ void fd_lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <int NT, bool SMALL>
+__device__ __forceinline__ void fd_wait_vmcnt(int n)   // n wave-uniform, 0..31
+{
+#define QE_VMW(k) case k: __builtin_amdgcn_s_waitcnt(0x0f70 | ((k) & 15) | (((k) >> 4) << 14)); break;
+    switch (n) {
+        QE_VMW(0) QE_VMW(1) QE_VMW(2) QE_VMW(3) QE_VMW(4) QE_VMW(5) QE_VMW(6) QE_VMW(7) QE_VMW(8) QE_VMW(9) QE_VMW(10)
+        QE_VMW(11) QE_VMW(12) QE_VMW(13) QE_VMW(14) QE_VMW(15) QE_VMW(16) QE_VMW(17) QE_VMW(18) QE_VMW(19) QE_VMW(20)
+        QE_VMW(21) QE_VMW(22) QE_VMW(23) QE_VMW(24) QE_VMW(25) QE_VMW(26) QE_VMW(27) QE_VMW(28) QE_VMW(29) QE_VMW(30)
+        default: __builtin_amdgcn_s_waitcnt(0x0f70); break;
+    }
+#undef QE_VMW
+}
+
+template <int NT, bool SMALL, int FD_RING>
 __global__ __launch_bounds__(256, 2) void conv_flatd_kernel(const FlatdArgs a)
 {
-    using G = FdGeom<NT, SMALL>;
+    using G = FdGeom<NT, SMALL, FD_RING>;
+    constexpr int AHEAD = FD_RING - 1;
     constexpr int RS = G::RS;
     static_assert(SMALL || (NT & 1) == 1, "WIDE tiles need an odd tile count (row stride = odd multiple of 32 B)");
     static_assert(!SMALL || NT == 8, "SMALL tiles are 4 images x 2 column tiles");
@@ -263,8 +276,7 @@ __global__ __launch_bounds__(256, 2) void conv_flatd_kernel(const FlatdArgs a)
                                              (__attribute__((address_space(3))) void *)(buf + G::XBYTES + (256 * i + 64 * wave) * 16), 16, 0, 0);
     };
 
-    issue(0);
-    if (n_stages > 1) issue(1);
+    for (int s0 = 0; s0 < AHEAD && s0 < n_stages; ++s0) issue(s0);
 
     // S_x (per-pixel channel sums) is only needed by output channels with zw' != 0: decided per WAVE (its 32 channels),
     // so the prologue needs no workgroup barrier (a __syncthreads() here would drain the two stages just requested)
@@ -302,8 +314,9 @@ __global__ __launch_bounds__(256, 2) void conv_flatd_kernel(const FlatdArgs a)
         constexpr bool SX = decltype(sx_tag)::value;
         for (int s = 0; s < n_stages; ++s) {
             // stage s has landed for this wave once at most the pieces of stage s + 1 are still outstanding
-                if (s + 1 < n_stages) {
-                if (n_xi == PXW) __builtin_amdgcn_s_waitcnt(0x0f70 | (PXW + 2)); else __builtin_amdgcn_s_waitcnt(0x0f70 | (PXW + 1));
+            if (s + 1 < n_stages) {
+                const int rem = (AHEAD - 1) < (n_stages - 1 - s) ? (AHEAD - 1) : (n_stages - 1 - s);   // younger stages in flight
+                fd_wait_vmcnt(rem * (n_xi + 2));
             } else {
                 __builtin_amdgcn_s_waitcnt(0x0f70);
                 if (fix_lds >= 0) {
@@ -313,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void conv_flatd_kernel(const FlatdArgs a)
                 }
             }
             __builtin_amdgcn_s_barrier();             // ... for every wave; and ring slot (s + 2) % 3 has no reader left
-            if (s + 2 < n_stages) issue(s + 2);
+            if (s + AHEAD < n_stages) issue(s + AHEAD);
             // per 32-channel chunk: one asm statement = weight fragment + every activation fragment + their wait
             const uint32_t xb = smem_lds + (uint32_t)((s % FD_RING) * G::STAGE);
 #pragma unroll
@@ -471,18 +484,18 @@ int launch_flatd(const qe_qparam *x, const qe_qparam *w, const float *bias, cons
     const int64_t runs = ((int64_t)a.n_pix_tiles + a.chunk - 1) / a.chunk;
     const int64_t blocks = (runs + 7) / 8 * a.chunk * 8 * a.n_oc_tiles;
     if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
-    static const bool raised = [] {
-        bool ok = true;
-        ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_flatd_kernel<5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, FdGeom<5, false>::LDS) == hipSuccess;
-        ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_flatd_kernel<7, false>), hipFuncAttributeMaxDynamicSharedMemorySize, FdGeom<7, false>::LDS) == hipSuccess;
-        ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_flatd_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FdGeom<8, true>::LDS) == hipSuccess;
-        return ok;
-    }();
-    (void)raised;
-    constexpr size_t lds8 = FdGeom<8, true>::LDS, lds5 = FdGeom<5, false>::LDS, lds7 = FdGeom<7, false>::LDS;
-    if (var == 8) hipLaunchKernelGGL((conv_flatd_kernel<8, true>), dim3((unsigned)blocks), dim3(256), lds8, s, a);
-    else if (var == 5) hipLaunchKernelGGL((conv_flatd_kernel<5, false>), dim3((unsigned)blocks), dim3(256), lds5, s, a);
-    else hipLaunchKernelGGL((conv_flatd_kernel<7, false>), dim3((unsigned)blocks), dim3(256), lds7, s, a);
+    // ring depth 3 = two stages in flight, two workgroups per CU.  A 6-slot ring (one workgroup per CU, five stages in flight)
+    // was 25-60 % slower on every layer (profiles/r02i_flatd_ring.txt): the K loop is not bound by prefetch depth.
+#define QE_FD_LAUNCH(NTV, SM, RG)                                                                                          \
+    do {                                                                                                                    \
+        static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_flatd_kernel<NTV, SM, RG>),       \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, FdGeom<NTV, SM, RG>::LDS) == hipSuccess; \
+        (void)ok_;                                                                                                          \
+        constexpr size_t lds_ = FdGeom<NTV, SM, RG>::LDS;                                                                   \
+        hipLaunchKernelGGL((conv_flatd_kernel<NTV, SM, RG>), dim3((unsigned)blocks), dim3(256), lds_, s, a);                \
+    } while (0)
+    if (var == 8) QE_FD_LAUNCH(8, true, 3); else if (var == 5) QE_FD_LAUNCH(5, false, 3); else QE_FD_LAUNCH(7, false, 3);
+#undef QE_FD_LAUNCH
     QE_LAUNCH_CHECK();
     return QE_OK;
 }

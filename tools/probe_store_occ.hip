@@ -29,6 +29,36 @@ __global__ __launch_bounds__(256) void kflat(float *out, int N, int OC, int P, i
     }
 }
 
+// the conv epilogue's form of the flat store for 196-pixel planes: 4 passes of 8 rows; the 16 lanes that own the rows write
+// their accumulators into a patch laid out like the output (25 x ds_write_b128), the whole wave copies it out
+__global__ __launch_bounds__(256) void kflat_patch(float *out, int N, int OC, int P, int NT, int n_oc, long units, int chunk)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bid = blockIdx.x, idx = bid >> 3;
+    const int j = idx / n_oc, ot = idx - j * n_oc;
+    const int c = j / chunk;
+    const long pt = (long)(c * 8 + (bid & 7)) * chunk + (j - c * chunk);
+    if (pt >= units) return;
+    const int n = (int)pt;
+    float *out_w = out + ((size_t)n * OC + (size_t)ot * 128 + wave * 32) * P;
+    float *patch8 = lds + wave * (8 * 196);
+    const int col = lane & 31, h = lane >> 5;
+    for (int ps = 0; ps < 4; ++ps) {
+        if ((col >> 3) == ps) {
+            for (int t = 0; t < 7; ++t)
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int px = 32 * t + 8 * gq + 4 * h;
+                    if (px < 196) { const vf4 v = {(float)t, (float)gq, (float)col, (float)bid}; *reinterpret_cast<vf4 *>(patch8 + (col & 7) * 196 + px) = v; }
+                }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        float *dst = out_w + (size_t)(8 * ps) * 196;
+        for (int i = lane; i < 8 * 49; i += 64) *reinterpret_cast<vf4 *>(dst + 4 * i) = *reinterpret_cast<const vf4 *>(patch8 + 4 * i);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+}
+
 template <bool PATCH>
 __global__ __launch_bounds__(256) void k(float *out, int N, int OC, int P, int NT, int n_oc, long units, int chunk)
 {
@@ -86,6 +116,17 @@ int main()
             (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
             float ms; (void)hipEventElapsedTime(&ms, e0, e1);
             printf("N=%d OC=%d P=%d  flat contiguous runs per wave: %.4f ms  %.2f TB/s\n", s.N, s.OC, s.P, ms / 12, bytes / (ms / 12) / 1e9);
+            if (s.P == 196) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kflat_patch), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+                for (int lk : {26, 72}) {
+                    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kflat_patch, dim3(blocks), dim3(256), lk * 1024, 0, tgt(), s.N, s.OC, s.P, s.NT, n_oc, units, chunk);
+                    (void)hipEventRecord(e0);
+                    for (int i = 0; i < 12; ++i) hipLaunchKernelGGL(kflat_patch, dim3(blocks), dim3(256), lk * 1024, 0, tgt(), s.N, s.OC, s.P, s.NT, n_oc, units, chunk);
+                    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+                    (void)hipEventElapsedTime(&ms, e0, e1);
+                    printf("N=%d OC=%d P=%d  flat through 4 x 8-row patches (LDS %d KB/WG): %.4f ms  %.2f TB/s\n", s.N, s.OC, s.P, lk, ms / 12, bytes / (ms / 12) / 1e9);
+                }
+            }
         }
         const size_t bytes = (size_t)s.N * s.OC * s.P * 4;
         const int per_buf = (int)(maxb / bytes);      // sub-buffers inside each allocation
