@@ -189,6 +189,7 @@ struct MfmaPlan {
     int GI = 1, NS = 1;
     bool flat = false, wraw = false, ws = false, s2 = false, sm2 = false;
     bool expand = false;       // sub-8-bit activations are expanded to 8-bit codes in the workspace first
+    bool x4 = false;           // 4-bit activations read from the packed stream by the flat kernel itself
     size_t xe_off = 0;
     bool flatg = false;        // flat 1x1 kernel for small planes (several whole images per tile)
     bool sub = false;          // strided 1x1: the sampled pixels are gathered into a dense tensor first
@@ -205,7 +206,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static const int kNiw[3][3] = {{7, 4, 2}, {4, 2, 1}, {2, 1, 0}};
 static const int kWN[3] = {1, 2, 4};
 
-static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits)
+static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits, bool x4 = false)
 {
     MfmaPlan p;
     p.OH = (sh->H + 2 * sh->padding - sh->KH) / sh->stride + 1;
@@ -292,7 +293,7 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits)
         p.lds = std::max((size_t)(32 * p.NS) * rstr, (size_t)4 * 32 * 36 * 4) + (size_t)ntp * 4;
         p.TH = 1; p.ni = tiles; p.niw = tiles / kWN[p.cfg];
         p.NCH = nch; p.NG = 2 * nch;
-        p.wraw = (w_bits == 8) && (sh->IC % 16) == 0;
+        p.wraw = (w_bits == 8) && (sh->IC % 16) == 0 && !x4;   // the 4-bit-activation instances take prepared fragments only
         p.wt_bytes = p.wraw ? 0 : (size_t)p.NG * p.OCP * 16;
         p.IHT = (P + ntp - 1) / ntp;   // pixel tiles per image
     } else
@@ -451,6 +452,16 @@ static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits, int w_bits)
     const bool sub = sh->KH == 1 && sh->KW == 1 && sh->stride > 1 && sh->padding == 0 && xb == 8 && sub_env != 0 &&
                      (sub_env > 0 || p_out <= 256);
     const qe_conv_shape ds = dense_shape(sh);
+    // 4-bit activations on a stride-1 1x1 layer with 128-channel workgroups: the flat kernel unpacks the nibbles in its
+    // staging registers (QE_X4=0: expansion pass + 8-bit kernel as for every other sub-8-bit case)
+    if (x_bits == 4 && expand && !sub && !(getenv("QE_X4") && atoi(getenv("QE_X4")) == 0)) {
+        MfmaPlan q = make_plan8(sh, 8, w_bits, true);
+        if (q.ok && q.flat && !q.s2 && !q.flatg && q.cfg == 0) {
+            q.x4 = true;
+            q.prep_total = q.total;
+            return q;
+        }
+    }
     MfmaPlan p = make_plan8(sub ? &ds : sh, xb, w_bits);
     p.prep_total = p.ok ? p.total : 0;
     if (p.ok && sub) {
@@ -739,6 +750,11 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     }
     if (p.flatg) {
         launch_mfma_flatg(a, p.NS, p.wraw, (unsigned)blocks, p.lds, s);
+        QE_LAUNCH_CHECK();
+        return QE_OK;
+    }
+    if (p.flat && p.x4) {
+        launch_mfma_flat_x4(a, p.niw, p.NS, (unsigned)blocks, p.lds, s);
         QE_LAUNCH_CHECK();
         return QE_OK;
     }

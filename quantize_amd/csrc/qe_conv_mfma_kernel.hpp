@@ -1369,9 +1369,12 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_smallic_kernel(const 
 // ---------------------------------------------------------------------------------------------
 typedef int v2i __attribute__((ext_vector_type(2)));
 
-template <int WM, int WN, int NIW, int NS, bool WRAW, bool S2>
+// X4: 4-bit activations consumed straight from the packed stream (a piece = 16 pixels = 8 bytes, nibbles spread to bytes
+// in the staging registers) instead of being expanded to 8-bit codes by a pass of their own first.
+template <int WM, int WN, int NIW, int NS, bool WRAW, bool S2, bool X4 = false>
 __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const MfmaArgs a)
 {
+    static_assert(!(X4 && S2), "the stride-2 staging takes 8-bit codes");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     constexpr int MT = 32 * WM;
@@ -1423,7 +1426,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
     // The read is clamped to end at the plane's end (P >= 16); a clamped piece is rotated back by
     // whole dwords (P % 4 == 0), so no read ever leaves the tensor.
     const int64_t img = (int64_t)n * a.IC * PIN;
-    const uint8_t *xi = a.x + img;
+    const uint8_t *xi = a.x + (X4 ? img / 2 : img);     // X4: two pixels per byte (PIN % 4 == 0: images start on a byte)
     int pc[PPT];          // channel within the stage
     int poff[PPT];        // clamped pixel offset inside the plane
     int prot[PPT];        // dwords to rotate (0 = piece was not clamped)
@@ -1480,14 +1483,19 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
     const int i16 = lane & 15;
     const int tr_base = (16 * h + (i16 >> 1)) * RSTR + 16 * ((lane >> 4) & 1) + 8 * (i16 & 1);
 
-    uint4 d[PPT];
+    std::conditional_t<X4, uint2, uint4> d[PPT];
     auto issue_x = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             const int cg = s * CK + pc[i];
             const int cgc = cg < a.IC ? cg : a.IC - 1;
-            const uint8_t *src = xi + (uint32_t)(cgc * PIN + poff[i]);
-            __builtin_memcpy(&d[i], src, 16);     // one (4-byte aligned) global_load_dwordx4
+            if constexpr (X4) {
+                const uint8_t *src = xi + ((uint32_t)(cgc * PIN + poff[i]) >> 1);   // element offsets are multiples of 4
+                __builtin_memcpy(&d[i], src, 8);  // one (2-byte aligned) global_load_dwordx2 = 16 pixels
+            } else {
+                const uint8_t *src = xi + (uint32_t)(cgc * PIN + poff[i]);
+                __builtin_memcpy(&d[i], src, 16);     // one (4-byte aligned) global_load_dwordx4
+            }
         }
     };
     issue_x(0);   // in flight while the zero-point test below synchronises the workgroup
@@ -1501,14 +1509,32 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
     auto stage_x = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
-            uint32_t v0 = d[i].x, v1 = d[i].y, v2 = d[i].z, v3 = d[i].w;
+            uint32_t v0, v1, v2, v3;
+            if constexpr (X4) {
+                // 16 nibbles -> 16 bytes (4 pixels per dword), then stored code u -> operand a = u - 8 (signed) | u
+                auto spread = [](uint32_t h16) __attribute__((always_inline)) -> uint32_t {
+                    uint32_t x = h16 & 0xffffu;
+                    x = (x | (x << 8)) & 0x00ff00ffu;
+                    return (x | (x << 4)) & 0x0f0f0f0fu;
+                };
+                auto to_op = [&](uint32_t u) __attribute__((always_inline)) -> uint32_t {
+                    if (!a.x_sign) return u;
+                    const uint32_t t = u ^ 0x08080808u;                     // q >= 0: t = q; q < 0: t = q + 16
+                    return t | ((t & 0x08080808u) * 30u);                   // ... sign-extend the nibble (8 * 30 = 0xF0 per byte)
+                };
+                v0 = to_op(spread(d[i].x)); v1 = to_op(spread(d[i].x >> 16));
+                v2 = to_op(spread(d[i].y)); v3 = to_op(spread(d[i].y >> 16));
+            } else {
+                v0 = d[i].x; v1 = d[i].y; v2 = d[i].z; v3 = d[i].w;
+            }
             // rotate a clamped tail piece back: out[j] = in[(j + rot) & 3]; rot is 0 almost everywhere
             const int rot = prot[i];
             const uint32_t r0 = rot == 0 ? v0 : (rot == 1 ? v1 : (rot == 2 ? v2 : v3));
             const uint32_t r1 = rot == 0 ? v1 : (rot == 1 ? v2 : (rot == 2 ? v3 : v0));
             const uint32_t r2 = rot == 0 ? v2 : (rot == 1 ? v3 : (rot == 2 ? v0 : v1));
             const uint32_t r3 = rot == 0 ? v3 : (rot == 1 ? v0 : (rot == 2 ? v1 : v2));
-            const uint4 w4 = make_uint4(r0 ^ 0x80808080u, r1 ^ 0x80808080u, r2 ^ 0x80808080u, r3 ^ 0x80808080u);
+            constexpr uint32_t XR = X4 ? 0u : 0x80808080u;      // 8-bit codes: u - 128 (signed q, or unsigned q - 128)
+            const uint4 w4 = make_uint4(r0 ^ XR, r1 ^ XR, r2 ^ XR, r3 ^ XR);
             if constexpr (S2) {
                 if (plds[i] >= 0) {
                     // keep the even columns: bytes 0,2 of each dword
@@ -1876,6 +1902,7 @@ void launch_mfma_ws(const MfmaArgs &a, int niw, int split, unsigned blocks, size
 void launch_mfma_sm2(const MfmaArgs &a, int wms, int split, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_flatg(const MfmaArgs &a, int ns, bool wraw, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_flat(const MfmaArgs &a, int cfg, int niw, int ns, bool wraw, bool s2, unsigned blocks, size_t lds, hipStream_t s);
+void launch_mfma_flat_x4(const MfmaArgs &a, int niw, int ns, unsigned blocks, size_t lds, hipStream_t s);
 
 #define QE_MFMA_K(WM, WN, NIW, KKT, X8, NS) \
     hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, NIW, KKT, X8, NS>), dim3(blocks), dim3(MF_THREADS), lds, s, a)

@@ -97,26 +97,33 @@ __global__ __launch_bounds__(TP_THREADS) void tpack_kernel(
             if constexpr (QM == 2) return (pl0 + (r0 + o) / q.inner) % q.n_ch; else return 0u;
         };
 
-        // (1) coalesced loads: iteration k covers elements base + k*1024 + 4*tid .. +3
+        // (1) coalesced loads, 16 bytes per lane where the element type allows: a lane takes EPL consecutive elements
+        // (16 for 1-byte inputs, 8 for 2-byte, 4 otherwise); iteration k covers elements base + k*256*EPL + EPL*tid ..
+        // (with 4 one-byte elements per lane, int8 / uint8 inputs packed at 2.0-2.2 TB/s: 4-byte loads)
+        constexpr int EPL = sizeof(T) == 1 ? 16 : (sizeof(T) == 2 ? 8 : 4);
 #pragma unroll
-        for (int k = 0; k < TP_EPT / 4; ++k) {
-            const uint32_t o = (uint32_t)(k * (TP_THREADS * 4) + tid * 4);
-            const int64_t e = base + o;
-            unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-            if (e + 3 < n && in_aligned && (QM != 2 || (q.inner & 3u) == 0)) {   // 4 elements of one channel
-                const Vec4<T> v = *reinterpret_cast<const Vec4<T> *>(x + e);
-                const uint32_t ch = chan(o);
-                c0 = code(v.v[0], ch);
-                c1 = code(v.v[1], ch);
-                c2 = code(v.v[2], ch);
-                c3 = code(v.v[3], ch);
-            } else {
-                if (e + 0 < n) c0 = code(x[e + 0], chan(o));
-                if (e + 1 < n) c1 = code(x[e + 1], chan(o + 1));
-                if (e + 2 < n) c2 = code(x[e + 2], chan(o + 2));
-                if (e + 3 < n) c3 = code(x[e + 3], chan(o + 3));
+        for (int k = 0; k < TP_EPT / EPL; ++k) {
+            const uint32_t o0 = (uint32_t)(k * (TP_THREADS * EPL) + tid * EPL);
+#pragma unroll
+            for (int v4 = 0; v4 < EPL / 4; ++v4) {
+                const uint32_t o = o0 + 4 * v4;
+                const int64_t e = base + o;
+                unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+                if (e + 3 < n && in_aligned && (QM != 2 || (q.inner & 3u) == 0)) {   // 4 elements of one channel
+                    const Vec4<T> v = *reinterpret_cast<const Vec4<T> *>(x + e);      // adjacent Vec4 loads merge into one 16-byte load
+                    const uint32_t ch = chan(o);
+                    c0 = code(v.v[0], ch);
+                    c1 = code(v.v[1], ch);
+                    c2 = code(v.v[2], ch);
+                    c3 = code(v.v[3], ch);
+                } else {
+                    if (e + 0 < n) c0 = code(x[e + 0], chan(o));
+                    if (e + 1 < n) c1 = code(x[e + 1], chan(o + 1));
+                    if (e + 2 < n) c2 = code(x[e + 2], chan(o + 2));
+                    if (e + 3 < n) c3 = code(x[e + 3], chan(o + 3));
+                }
+                s_codes[o >> 2] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
             }
-            s_codes[k * TP_THREADS + tid] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
         }
         __syncthreads();
 

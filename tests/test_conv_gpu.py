@@ -292,17 +292,21 @@ def test_kernel_variants_forced_by_env(engine, env):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("expand", ["0", "1"])
-def test_sub8_activation_paths(engine, expand):
-    """b < 8 activations either decode inside the halo kernel (QE_EXPAND=0) or are expanded once to 8-bit codes in
-    the workspace and run on the 8-bit kernels (default); both meet the parity bar, incl. asymmetric zero points."""
+@pytest.mark.parametrize("expand,x4", [("0", "1"), ("1", "1"), ("1", "0")])
+def test_sub8_activation_paths(engine, expand, x4):
+    """b < 8 activations either decode inside the halo kernel (QE_EXPAND=0), or are expanded once to 8-bit codes in
+    the workspace and run on the 8-bit kernels (default), or -- 4-bit activations on stride-1 1x1 layers -- are unpacked
+    by the flat kernel's own staging (QE_X4, default on); all meet the parity bar, incl. asymmetric zero points."""
     import os
     rng = np.random.RandomState(23)
     old = os.environ.get("QE_EXPAND")
+    oldx = os.environ.get("QE_X4")
     os.environ["QE_EXPAND"] = expand
+    os.environ["QE_X4"] = x4
     try:
         for shp in [(2, 64, 28, 28, 160, 1, 1, 0), (2, 128, 14, 14, 130, 3, 1, 1), (3, 64, 56, 56, 64, 3, 1, 1),
-                    (2, 3, 37, 41, 24, 7, 2, 3), (2, 96, 28, 28, 130, 1, 2, 0), (5, 96, 7, 7, 64, 1, 1, 0)]:
+                    (2, 3, 37, 41, 24, 7, 2, 3), (2, 96, 28, 28, 130, 1, 2, 0), (5, 96, 7, 7, 64, 1, 1, 0),
+                    (2, 256, 56, 56, 130, 1, 1, 0), (3, 160, 14, 14, 200, 1, 1, 0), (2, 48, 10, 18, 136, 1, 1, 0)]:
             for (wb, wsgn, ab, asgn) in [(4, 1, 4, 1), (8, 1, 4, 0), (3, 0, 6, 1), (8, 0, 1, 0)]:
                 for zeros in (False, True):
                     case = _random_case(rng, *shp, wb, wsgn, ab, asgn, w_pc=True, a_pc=False, zeros=zeros, bias=True)
@@ -310,10 +314,11 @@ def test_sub8_activation_paths(engine, expand):
                     assert case["path"] == 1
                     _assert_conv_close(y, o64, o32, "expand=%s %s %s zeros=%s" % (expand, shp, (wb, wsgn, ab, asgn), zeros), case["fma"])
     finally:
-        if old is None:
-            os.environ.pop("QE_EXPAND", None)
-        else:
-            os.environ["QE_EXPAND"] = old
+        for k, v in (("QE_EXPAND", old), ("QE_X4", oldx)):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def test_4bit_weights_on_flat_kernels(engine):
