@@ -45,18 +45,22 @@ struct FlatdArgs {
 
 constexpr int FD_CK = 64;              // channels per stage
 constexpr int FD_RING_DEFAULT = 3;      // slots of the ring (RING - 1 stages in flight); 6 = one workgroup per CU with 5 in flight
-constexpr int FD_MT = 128;             // output channels per workgroup (4 waves x 32)
-constexpr int FD_WBYTES = FD_MT * FD_CK;
+// output channels per workgroup = 32 per wave: 4 waves (128 channels, two workgroups per CU) or 8 waves (256 channels, one
+// workgroup per CU: the activations of a pixel tile cross the CU's memory path once per 256 output channels instead of
+// once per 128 -- the bytes that bound these layers)
 
-template <int NT, bool SMALL, int RING = FD_RING_DEFAULT> struct FdGeom {
+template <int NT, bool SMALL, int RING = FD_RING_DEFAULT, int WAVES = 4> struct FdGeom {
+    static constexpr int MT = 32 * WAVES;
+    static constexpr int THREADS = 64 * WAVES;
+    static constexpr int FD_WBYTES = MT * FD_CK;
     static constexpr int RS = SMALL ? 64 : 32 * NT;                  // LDS bytes per channel row (WIDE: NT odd)
     static constexpr int XBYTES = SMALL ? 4 * FD_CK * 64 : FD_CK * RS;
     static constexpr int STAGE = XBYTES + FD_WBYTES;
     static constexpr int XINSTR = XBYTES / 1024;                     // wave-level DMA instructions per stage
     static constexpr int NTP = 32 * NT;
-    static constexpr int PATCH = SMALL ? 4 * 32 * 49 * 4 : 4 * 32 * 36 * 4;
+    static constexpr int PATCH = SMALL ? WAVES * 32 * 49 * 4 : WAVES * 32 * 36 * 4;
     static constexpr int RING_BYTES = RING * STAGE > PATCH ? RING * STAGE : PATCH;
-    static constexpr int LDS = RING_BYTES + 4 * NTP * 4 /* S_x, one copy per wave */;
+    static constexpr int LDS = RING_BYTES + WAVES * NTP * 4 /* S_x, one copy per wave */;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -162,11 +166,12 @@ __device__ __forceinline__ void fd_wait_vmcnt(int n)   // n wave-uniform, 0..31
 #undef QE_VMW
 }
 
-template <int NT, bool SMALL, int FD_RING>
-__global__ __launch_bounds__(256, 2) void conv_flatd_kernel(const FlatdArgs a)
+template <int NT, bool SMALL, int FD_RING, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void conv_flatd_kernel(const FlatdArgs a)
 {
-    using G = FdGeom<NT, SMALL, FD_RING>;
+    using G = FdGeom<NT, SMALL, FD_RING, WAVES>;
     constexpr int AHEAD = FD_RING - 1;
+    constexpr int FD_MT = G::MT, THREADS = G::THREADS;
     constexpr int RS = G::RS;
     static_assert(SMALL || (NT & 1) == 1, "WIDE tiles need an odd tile count (row stride = odd multiple of 32 B)");
     static_assert(!SMALL || NT == 8, "SMALL tiles are 4 images x 2 column tiles");
@@ -203,15 +208,15 @@ __global__ __launch_bounds__(256, 2) void conv_flatd_kernel(const FlatdArgs a)
 
     // ---- DMA sources (stage 0; a stage advances X by 64 planes and W by 64 bytes) ------------------------------
     // X: LDS slot e = 64 * (wave-instruction q) + lane, q = wave, wave + 4, ...
-    constexpr int PXW = (G::XINSTR + 3) / 4;          // X instructions of waves 0 .. (XINSTR % 4) - 1 (the others issue one less)
-    const int n_xi = (G::XINSTR % 4 == 0 || wave < G::XINSTR % 4) ? PXW : PXW - 1;
+    constexpr int PXW = (G::XINSTR + WAVES - 1) / WAVES;   // X instructions of waves 0 .. (XINSTR % WAVES) - 1 (the others issue one less)
+    const int n_xi = (G::XINSTR % WAVES == 0 || wave < G::XINSTR % WAVES) ? PXW : PXW - 1;
     const int64_t x_last16 = (int64_t)a.N * a.IC * P - 16;      // last address a 16-byte read may start at
     const uint8_t *px[PXW];
     int fix_lds = -1, fix_i = -1;                      // this thread writes the tensor's last bytes itself (last stage only)
     uint32_t fix_val = 0;
 #pragma unroll
     for (int i = 0; i < PXW; ++i) {
-        const int e = 64 * (wave + 4 * i) + lane;
+        const int e = 64 * (wave + WAVES * i) + lane;
         int64_t src;
         bool last_row;
         int j;
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void conv_flatd_kernel(const FlatdArgs a)
     const uint8_t *pw[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int e = tid + 256 * i;
+        const int e = tid + THREADS * i;
         const int r = e >> 2, sl = e & 3;
         const int orow = ot * FD_MT + r < a.OC ? ot * FD_MT + r : a.OC - 1;
         pw[i] = a.w + (int64_t)orow * a.IC + 16 * (sl ^ ((r >> 2) & 3));
@@ -268,12 +273,12 @@ __global__ __launch_bounds__(256, 2) void conv_flatd_kernel(const FlatdArgs a)
         for (int i = 0; i < PXW; ++i) {
             if (i < n_xi && i != skip)    // first term wave-uniform, second per lane (EXEC mask)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(px[i] + s * x_step),
-                                                 (__attribute__((address_space(3))) void *)(buf + 1024 * (wave + 4 * i)), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(buf + 1024 * (wave + WAVES * i)), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pw[i] + s * FD_CK),
-                                             (__attribute__((address_space(3))) void *)(buf + G::XBYTES + (256 * i + 64 * wave) * 16), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(buf + G::XBYTES + (THREADS * i + 64 * wave) * 16), 16, 0, 0);
     };
 
     for (int s0 = 0; s0 < AHEAD && s0 < n_stages; ++s0) issue(s0);
@@ -472,7 +477,13 @@ int launch_flatd(const qe_qparam *x, const qe_qparam *w, const float *bias, cons
     a.x_scale = x->scale; a.x_zero = x->zero; a.w_scale = w->scale; a.w_zero = w->zero; a.bias = bias;
     a.x_sign = x->sign; a.w_sign = w->sign; a.w_per_tensor = (w->n_param == 1);
     a.out = out; a.N = sh->N; a.IC = sh->IC; a.OC = sh->OC; a.P = sh->H * sh->W;
-    a.n_oc_tiles = (sh->OC + FD_MT - 1) / FD_MT;
+    // 8-wave / 256-channel workgroups: measured (profiles/r02l_flatd_w8.txt) -9 % on 512->2048 @7x7, +-3 % on the 14x14
+    // layers, +15 % on 2048->512 @7x7 -- halving the activation re-reads does NOT give the -14..-26 % a bytes-through-the-CU
+    // model predicts.  On for wide 7x7 layers only; QE_FLATD8=0 | 1 overrides.
+    bool w8 = var == 8 && sh->OC >= 1024;
+    if (const char *e8 = getenv("QE_FLATD8")) w8 = atoi(e8) != 0 && sh->OC > 128;
+    const int MT = w8 ? 256 : 128;
+    a.n_oc_tiles = (sh->OC + MT - 1) / MT;
     if (var == 8) { a.tiles_per_image = 1; a.n_pix_tiles = (sh->N + 3) / 4; }
     else { a.tiles_per_image = (a.P + 32 * var - 1) / (32 * var); a.n_pix_tiles = sh->N * a.tiles_per_image; }
     const int64_t per_xcd = ((int64_t)a.n_pix_tiles + 7) / 8;
@@ -486,15 +497,19 @@ int launch_flatd(const qe_qparam *x, const qe_qparam *w, const float *bias, cons
     if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
     // ring depth 3 = two stages in flight, two workgroups per CU.  A 6-slot ring (one workgroup per CU, five stages in flight)
     // was 25-60 % slower on every layer (profiles/r02i_flatd_ring.txt): the K loop is not bound by prefetch depth.
-#define QE_FD_LAUNCH(NTV, SM, RG)                                                                                          \
+#define QE_FD_LAUNCH(NTV, SM, RG, WV)                                                                                      \
     do {                                                                                                                    \
-        static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_flatd_kernel<NTV, SM, RG>),       \
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, FdGeom<NTV, SM, RG>::LDS) == hipSuccess; \
+        static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_flatd_kernel<NTV, SM, RG, WV>),   \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, FdGeom<NTV, SM, RG, WV>::LDS) == hipSuccess; \
         (void)ok_;                                                                                                          \
-        constexpr size_t lds_ = FdGeom<NTV, SM, RG>::LDS;                                                                   \
-        hipLaunchKernelGGL((conv_flatd_kernel<NTV, SM, RG>), dim3((unsigned)blocks), dim3(256), lds_, s, a);                \
+        constexpr size_t lds_ = FdGeom<NTV, SM, RG, WV>::LDS;                                                               \
+        hipLaunchKernelGGL((conv_flatd_kernel<NTV, SM, RG, WV>), dim3((unsigned)blocks), dim3(64 * WV), lds_, s, a);        \
     } while (0)
-    if (var == 8) QE_FD_LAUNCH(8, true, 3); else if (var == 5) QE_FD_LAUNCH(5, false, 3); else QE_FD_LAUNCH(7, false, 3);
+    if (w8) {
+        if (var == 8) QE_FD_LAUNCH(8, true, 3, 8); else if (var == 5) QE_FD_LAUNCH(5, false, 3, 8); else QE_FD_LAUNCH(7, false, 3, 8);
+    } else {
+        if (var == 8) QE_FD_LAUNCH(8, true, 3, 4); else if (var == 5) QE_FD_LAUNCH(5, false, 3, 4); else QE_FD_LAUNCH(7, false, 3, 4);
+    }
 #undef QE_FD_LAUNCH
     QE_LAUNCH_CHECK();
     return QE_OK;
