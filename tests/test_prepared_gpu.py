@@ -78,9 +78,10 @@ def test_module_caches_hit_and_invalidate(engine):
     t = dict(xp=_t(xp), xd=_t(xd), sx=_t(sx), zx=_t(zx), wp=_t(wp), wd=_t(wd), sw=_t(sw).reshape(-1, 1, 1, 1),
              zw=_t(zw).reshape(-1, 1, 1, 1), b=_t(case["bias"]))
     call = lambda: engine.quantconv2d(t["xp"], t["xd"], t["sx"], t["zx"], t["wp"], t["wd"], t["sw"], t["zw"], t["b"], 1, 1)
+    sb = quant_engine.cache_stats()             # the counters are cumulative over the process: compare differences
     y0 = call()
     s0 = quant_engine.cache_stats()
-    assert s0[1] == 2 and s0[3] == 1            # two descriptions parsed, one weight set prepared
+    assert s0[1] - sb[1] == 2 and s0[3] - sb[3] == 1 and s0[4:] == [2, 1]   # two descriptions parsed, one weight set prepared
     y1 = call()
     s1 = quant_engine.cache_stats()
     assert s1[0] == s0[0] + 2 and s1[2] == s0[2] + 1 and s1[1] == s0[1] and s1[3] == s0[3]   # all hits, no new misses

@@ -7,7 +7,8 @@ rows = []
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-main = [i for i, r in enumerate(rows) if "conv_mfma" in r["Kernel_Name"] and "prep" not in r["Kernel_Name"]]
+is_conv = lambda n: ("conv_mfma" in n or "conv_flatd" in n) and "prep" not in n
+main = [i for i, r in enumerate(rows) if is_conv(r["Kernel_Name"])]
 assert len(main) % 53 == 0, len(main)
 first = main[-53]
 # include a prep kernel that belongs to the first layer of the step
@@ -25,7 +26,7 @@ for r in rows[first:last + 1]:
     short = name.split("(")[0].replace("void qe::", "")[:60]
     gap = (s - t_prev) / 1e3 if t_prev is not None else 0.0
     dur = (e - s) / 1e3
-    is_prep = "conv_mfma" not in name or "prep" in name   # weight prep, strided gather, code expansion
+    is_prep = not is_conv(name)   # weight prep, strided gather, code expansion
     if not is_prep:
         layer += 1
         tot_main += dur
