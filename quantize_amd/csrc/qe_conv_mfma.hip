@@ -180,6 +180,11 @@ __global__ __launch_bounds__(64) void conv_mfma_prep_smallic_kernel(const PrepAr
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+bool sm2d_plan(const qe_conv_shape *sh, int waves, int *GI, int *TH, int *niw, size_t *lds);                    // qe_conv_halod.hip
+int sm2d_ptab_off(int GI, int IHT, int IWP, int W, int waves);
+void launch_mfma_sm2d(const MfmaArgs &a, int niw, int waves, unsigned blocks, size_t lds, hipStream_t s);
+constexpr int QE_SM2D_DEFAULT = 0;
+
 struct MfmaPlan {
     bool ok = false;
     int cfg = 0;       // 0: 4x1 waves (MT 128), 1: 2x2 (MT 64), 2: 1x4 (MT 32)
@@ -188,6 +193,7 @@ struct MfmaPlan {
     bool smallic = false;
     int GI = 1, NS = 1;
     bool flat = false, wraw = false, ws = false, s2 = false, sm2 = false;
+    int sm2d = 0;              // 3x3 / stride 1: both operands by LDS-DMA (qe_conv_halod.hip); value = waves per workgroup (4 | 8)
     bool expand = false;       // sub-8-bit activations are expanded to 8-bit codes in the workspace first
     bool x4 = false;           // 4-bit activations read from the packed stream by the flat kernel itself
     size_t xe_off = 0;
@@ -303,8 +309,23 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits, bool
     // QE_SM2 0 1): 56x56 64->64 0.083 -> 0.068 ms, 14x14 256->256 0.050 -> 0.048, 28x28 +4 %, 7x7 maps and the
     // stride-2 layers +15 % (the warp-specialised kernel / bigger halo tiles win there).  Default: stride 1 and a
     // tile that is either 64 channels wide or a whole image; QE_SM2=1 forces it wherever it fits, QE_SM2=0 never.
+    // 3x3 / stride 1 / pad 1, 8-bit activations, > 64 output channels, IC % 32 == 0: the LDS-DMA kernel (qe_conv_halod.hip).
+    // QE_SM2D=0 keeps the register-staged kernels below.
+    const int sm2d_env = getenv("QE_SM2D") ? atoi(getenv("QE_SM2D")) : QE_SM2D_DEFAULT;   // 1: 8 waves, 2: 4 waves
+    if (!p.flat && !p.flatg && !p.smallic && p.KK == 9 && x_bits == 8 && p.cfg == 0 && sm2d_env != 0) {
+        int GI, TH, niw;
+        size_t lds;
+        const int waves = sm2d_env == 1 ? 8 : 4;
+        if (sm2d_plan(sh, waves, &GI, &TH, &niw, &lds)) {
+            p.sm2d = waves; p.GI = GI; p.TH = TH; p.IHT = TH + 2; p.IWP = p.OW + 2; p.lds = lds; p.NS = 1;
+            p.NCH = sh->IC / 32; p.NG = 2 * p.NCH;
+            p.ni = (GI * TH * p.OW + 31) / 32; p.niw = niw;
+            p.wt_bytes = (size_t)p.KK * p.NG * p.OCP * 16;
+            if ((int64_t)p.wt_bytes >= (1ll << 31)) { p.sm2d = 0; p.GI = 1; p.TH = 0; }
+        }
+    }
     const int sm2_env = getenv("QE_SM2") ? atoi(getenv("QE_SM2")) : -1;
-    if (!p.flat && !p.flatg && !p.smallic && p.KK == 9 && sh->KW == 3 && sh->KH == 3 && x_bits == 8 && p.cfg <= 1 && sm2_env != 0) {
+    if (!p.sm2d && !p.flat && !p.flatg && !p.smallic && p.KK == 9 && sh->KW == 3 && sh->KH == 3 && x_bits == 8 && p.cfg <= 1 && sm2_env != 0) {
         const int max_px = 32 * (p.cfg == 0 ? 8 : 16);
         int GI = 1;
         if (p.OH * p.OW <= max_px / 2) GI = std::max(1, std::min((int)sh->N, max_px / (p.OH * p.OW)));
@@ -334,7 +355,7 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits, bool
             if (!p.sm2) { p.GI = 1; p.TH = 0; p.NS = 1; }   // the halo plan below starts from scratch
         }
     }
-    if (p.flat || p.flatg || p.sm2) {
+    if (p.flat || p.flatg || p.sm2 || p.sm2d) {
     } else if (p.smallic) {
         // stem layout: K = (kh) x [kw 0..7][ic 0..3]; the whole (tiny) channel depth is one stage
         p.NCH = 1;
@@ -727,7 +748,9 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     // LDS room for the epilogue's copy of the tile's S_w prefix rows (asymmetric activations; stage_ptab)
     size_t lds_e = p.lds;
     a.ptab_off = 0;
-    if (!p.flat && !p.flatg) {
+    if (p.sm2d) {
+        a.ptab_off = sm2d_ptab_off(p.GI, p.IHT, p.IWP, sh->W, p.sm2d);   // the natural-order buffers are free once the K loop is done
+    } else if (!p.flat && !p.flatg) {
         const size_t tab = (size_t)p.MT * (sh->KH + 1) * (sh->KW + 1) * sizeof(int);
         const size_t off = align_up(p.lds, 16);
         if (off + tab <= (size_t)(p.sm2 ? MF_MAX_LDS_SM2 : MF_MAX_LDS)) { a.ptab_off = (int)off; lds_e = off + tab; }
@@ -760,6 +783,11 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     }
     if (p.flat) {
         launch_mfma_flat(a, p.cfg, p.niw, p.NS, p.wraw, p.s2, (unsigned)blocks, p.lds, s);
+        QE_LAUNCH_CHECK();
+        return QE_OK;
+    }
+    if (p.sm2d) {
+        launch_mfma_sm2d(a, p.niw, p.sm2d, (unsigned)blocks, p.lds, s);
         QE_LAUNCH_CHECK();
         return QE_OK;
     }

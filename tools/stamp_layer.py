@@ -10,7 +10,7 @@ import argparse
 from bench import Layer
 
 class A: pass
-args = A(); args.a_bits = 8; args.w_bits = 8; args.asymmetric = False
+args = A(); args.a_bits = 8; args.w_bits = 8; args.asymmetric = False; args.per_call_prepare = True; args.float_input = False
 L = capi.lib()
 dev = torch.device("cuda", 0)
 specs = resnet50.conv_layers()
