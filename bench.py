@@ -53,6 +53,12 @@ def parse_args():
     ap.add_argument("--float-input", action="store_true",
                     help="the quantconv2d_float_input operator instead: fp32 NCHW activations x packed weights on the same 53-layer "
                          "stack (22.32 GB algorithmic per batch-256); reported under its own metric name, never as the headline")
+    ap.add_argument("--fused-requant", action="store_true",
+                    help="SEPARATE measurement (not the headline contract, whose outputs are fp32): every conv stores the 8-bit "
+                         "codes of the consumer's activation quantiser instead (qe_quantconv2d_requant_prepared), 1 B per output")
+    ap.add_argument("--two-pass", action="store_true",
+                    help="with --fused-requant: produce the same codes the reference's way, conv to fp32 and then the fused "
+                         "quantise+pack kernel (qe_quantconv2d_prepared + qe_quantize_pack): the comparison line for the fused epilogue")
     ap.add_argument("--per-call-prepare", action="store_true",
                     help="re-lay-out the 3x3 / stem weights inside every call (qe_quantconv2d, as round 1 timed it) instead of "
                          "once per layer at set-up (qe_conv_prepare + qe_quantconv2d_prepared: a packed layer's weights do not "
@@ -115,7 +121,40 @@ class Layer:
         self.path = capi.conv_path(self.sh, self.xq, self.wq)
         self.bytes = resnet50.algorithmic_bytes(spec, N, args.a_bits, args.w_bits)
         self.ops = 2 * resnet50.macs_per_image(spec) * N
-        if self.prepared is None:
+        if getattr(args, "fused_requant", False):
+            # consumer's quantiser: per tensor, signed 8 bit, scale from the layer's own output statistics (one untimed call)
+            y = capi.quantconv2d_prepared(self.xq, self.wq, self.bias, self.sh, self.prepared)
+            self.rq_s = (y.abs().max() / 127.0).reshape(1).float()
+            self.rq_z = torch.zeros(1, device=dev)
+            del y
+            self.rq = capi.requant(self.rq_s, self.rq_z, -128.0, 127.0, 8, True)
+            self.fused = capi.requant_path(self.sh, self.xq, self.wq, self.rq)
+            need = int(L.qe_quantconv2d_requant_workspace_bytes(ctypes.byref(self.sh), ctypes.byref(self.xq), ctypes.byref(self.wq),
+                                                                ctypes.byref(self.rq)))
+            self.ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+            self.out = None
+            self.out_q = torch.empty(N * spec.OC * oh * ow, dtype=torch.uint8, device=dev)
+            self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.bytes = resnet50.algorithmic_bytes(spec, N, args.a_bits, args.w_bits) - 3 * N * spec.OC * oh * ow
+            pp = ctypes.c_void_p(self.prepared.data_ptr()) if self.prepared.numel() else None
+            self._call = (L.qe_quantconv2d_requant_prepared, ctypes.byref(self.xq), ctypes.byref(self.wq), bias_p,
+                          ctypes.byref(self.sh), pp, ctypes.c_size_t(self.prepared.numel()), ctypes.byref(self.rq),
+                          ctypes.c_void_p(self.out_q.data_ptr()), ctypes.c_void_p(self.status.data_ptr()),
+                          ctypes.c_void_p(self.ws.data_ptr()), ctypes.c_size_t(self.ws.numel()))
+            if getattr(args, "two_pass", False):
+                self.fused = 0
+                self.out = torch.empty((N, spec.OC, oh, ow), dtype=torch.float32, device=dev)
+                need = int(L.qe_quantconv2d_prepared_workspace_bytes(ctypes.byref(self.sh), args.a_bits, args.w_bits))
+                self.ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+                self._call = (L.qe_quantconv2d_prepared, ctypes.byref(self.xq), ctypes.byref(self.wq), bias_p,
+                              ctypes.byref(self.sh), pp, ctypes.c_size_t(self.prepared.numel()),
+                              ctypes.c_void_p(self.out.data_ptr()),
+                              ctypes.c_void_p(self.ws.data_ptr()), ctypes.c_size_t(self.ws.numel()))
+                self._call2 = (L.qe_quantize_pack, ctypes.c_void_p(self.out.data_ptr()), ctypes.c_int64(N * spec.OC * oh * ow),
+                               ctypes.c_void_p(self.rq_s.data_ptr()), ctypes.c_void_p(self.rq_z.data_ptr()), 1, ctypes.c_int64(oh * ow),
+                               ctypes.c_float(-128.0), ctypes.c_float(127.0), 8, 1, ctypes.c_void_p(self.out_q.data_ptr()),
+                               ctypes.c_void_p(self.status.data_ptr()))
+        elif self.prepared is None:
             self._call = (L.qe_quantconv2d, ctypes.byref(self.xq), ctypes.byref(self.wq), bias_p,
                           ctypes.byref(self.sh), ctypes.c_void_p(self.out.data_ptr()),
                           ctypes.c_void_p(self.ws.data_ptr()), ctypes.c_size_t(self.ws.numel()))
@@ -131,6 +170,11 @@ class Layer:
         rc = f[0](*f[1:], stream_ptr)
         if rc != 0:
             raise RuntimeError("conv call failed on layer %s: %d" % (self.spec.name, rc))
+        f2 = getattr(self, "_call2", None)
+        if f2 is not None:
+            rc = f2[0](*f2[1:], stream_ptr)
+            if rc != 0:
+                raise RuntimeError("quantize_pack call failed on layer %s: %d" % (self.spec.name, rc))
 
 
 def usable_cores():
@@ -253,7 +297,13 @@ def main():
         keep = [int(v) for v in args.layers.split(",")]
         specs = [specs[i] for i in keep]
     N = args.batch
-    layers = [Layer(i, sp, N, dev, args, rank, capi, resnet50, torch) for i, sp in enumerate(specs)]
+    if args.fused_requant:
+        assert not args.float_input and not args.per_call_prepare and args.a_bits == 8, "--fused-requant: W8A8-style packed path"
+        import copy
+        args_last = copy.copy(args)
+        args_last.fused_requant = False      # the last conv feeds the fp32 classifier head, not a quantiser
+    layers = [Layer(i, sp, N, dev, args_last if (args.fused_requant and i == len(specs) - 1) else args, rank, capi, resnet50, torch)
+              for i, sp in enumerate(specs)]
 
     # top-1 tail: avg-pool + synthetic fc on the last conv output, identical weights on every rank
     g = torch.Generator(device=dev)
@@ -378,7 +428,7 @@ def main():
         traffic, traffic_tag = None, None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath) and not args.layers and N == 256 and args.w_bits == 8 and args.a_bits == 8 \
-                and not args.asymmetric and not args.float_input:
+                and not args.asymmetric and not args.float_input and not args.fused_requant:
             try:
                 from quantize_amd.build import source_sha16
                 tj = json.load(open(tpath))
@@ -427,7 +477,19 @@ def main():
                          "int8_tops": total_ops / (conv_ms * 1e-3) / 1e12,
                          "mfma_frac": total_ops / (conv_ms * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.fused_requant:
+            n_f = sum(1 for L in layers if getattr(L, "fused", 0))
+            result["metric"] += ", fused re-quantisation (NOT the headline contract)"
+            result["config"]["workload"] = ("ResNet-50 conv stack (53 convs), W%dA%d packed-int quantconv2d with the consumer's 8-bit "
+                                            "activation quantiser fused into the epilogue: 1-byte NCHW codes out of 52 layers, fp32 out of "
+                                            "the last; %d layers store the codes from the conv kernel itself, %d take conv + quantise-pack "
+                                            "inside the call" % (args.w_bits, args.a_bits, n_f, len(layers) - 1 - n_f))
+            result["roofline"]["kernel"] = "the headline's kernels with the re-quantising epilogue (flatd layers on conv_mfma_flatg_kernel)"
+            result["roofline"]["note"] = "algorithmic bytes with 1 B per output element (activations in + weights + codes out)"
+            if args.two_pass:
+                result["metric"] = result["metric"].replace("fused re-quantisation", "re-quantisation in TWO passes (conv to fp32, then quantise+pack)")
+                result["roofline"]["kernel"] = "the headline's kernels + tpack_kernel<float, 8, 1> per layer (52 more launches)"
+        if world == 1 and not args.no_cpu_baseline and not args.fused_requant:
             # two legs on the box's host cores: the CPU port of the reference KERNEL (oracle) and the reference's own
             # packed-forward FALLBACK (F.conv2d on dequantised tensors), which is what north_star names
             result["cpu_baseline"] = cpu_baseline(layers, args, torch)

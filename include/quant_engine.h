@@ -172,6 +172,35 @@ int qe_quantconv2d_prepared(const qe_qparam *x, const qe_qparam *w, const float 
                             float *out, void *workspace, size_t workspace_bytes, qe_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * qe_quantconv2d_requant_prepared -- quantconv2d with the NEXT layer's activation quantiser fused into the epilogue
+ *   (conv-epilogue form).  reference: the packed forward of
+ *   modelzoo/modules/quantconv2d.py:198-210 followed by the consumer's Quantizer (quantizer.py:31,213-226) and
+ *   engine.tpack -- three passes over a 4 B/element tensor there, none here.
+ * out  qe_packed_nbytes(N*OC*OH*OW, rq->n_bits) bytes, bit-identical to
+ *      qe_quantize_pack(qe_quantconv2d_prepared(x, w, ...), rq->scale, rq->zero, rq->n_param, OH*OW, ...).
+ * rq   output quantiser in the MODULE's convention (q = round(y / scale - zero).clamp(qmin, qmax)); n_param = 1 (per
+ *      tensor) or OC (per output channel).
+ * qe_quantconv2d_requant_path: 1 = the conv kernel stores the codes itself (8-bit codes, per-tensor rq, MFMA-eligible problem);
+ *      0 = two passes inside the call (fp32 y in the workspace, then the quantise+pack kernel).
+ * workspace  qe_quantconv2d_requant_workspace_bytes(shape, x, w, rq) bytes, 16-byte aligned.
+ * prepared   as qe_quantconv2d_prepared (qe_conv_prepare); status as qe_tpack.
+ * ------------------------------------------------------------------------- */
+typedef struct qe_requant {
+    const float *scale;
+    const float *zero;
+    int32_t n_param;
+    float qmin, qmax;
+    int32_t n_bits, sign;
+} qe_requant;
+int qe_quantconv2d_requant_path(const qe_conv_shape *shape, const qe_qparam *x, const qe_qparam *w, const qe_requant *rq);
+size_t qe_quantconv2d_requant_workspace_bytes(const qe_conv_shape *shape, const qe_qparam *x, const qe_qparam *w,
+                                              const qe_requant *rq);
+int qe_quantconv2d_requant_prepared(const qe_qparam *x, const qe_qparam *w, const float *bias,
+                                    const qe_conv_shape *shape, const void *prepared, size_t prepared_bytes,
+                                    const qe_requant *rq, uint8_t *out, int32_t *status,
+                                    void *workspace, size_t workspace_bytes, qe_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * qe_quantconv2d_float_input -- replaces quantconv2d_float_input()/..._cuda
  *   reference: engine/kernels/functions/quantconv2d_float_input.cu:140-220, :45-121.
  * x        fp32[N*IC*H*W], NCHW contiguous.

@@ -22,7 +22,8 @@ SYMBOLS = ["qe_error_string", "qe_last_hip_error", "qe_version", "qe_target_arch
            "qe_quantlinear_path", "qe_global_avgpool", "qe_conv_prepared_bytes", "qe_quantconv2d_prepared_workspace_bytes",
            "qe_conv_prepare", "qe_quantconv2d_prepared", "qe_quantize_pack", "qe_quantconv2d_float_input_workspace_bytes",
            "qe_quantconv2d_float_input_ws", "qe_conv_f32_prepare", "qe_quantconv2d_float_input_prepared",
-           "qe_quantconv2d_float_input_path"]
+           "qe_quantconv2d_float_input_path", "qe_quantconv2d_requant_path", "qe_quantconv2d_requant_workspace_bytes",
+           "qe_quantconv2d_requant_prepared"]
 
 
 class QeConvShape(ctypes.Structure):
@@ -32,6 +33,11 @@ class QeConvShape(ctypes.Structure):
 class QeQParam(ctypes.Structure):
     _fields_ = [("data", ctypes.c_void_p), ("n_bits", ctypes.c_int32), ("sign", ctypes.c_int32),
                 ("scale", ctypes.c_void_p), ("zero", ctypes.c_void_p), ("n_param", ctypes.c_int32)]
+
+
+class QeRequant(ctypes.Structure):
+    _fields_ = [("scale", ctypes.c_void_p), ("zero", ctypes.c_void_p), ("n_param", ctypes.c_int32),
+                ("qmin", ctypes.c_float), ("qmax", ctypes.c_float), ("n_bits", ctypes.c_int32), ("sign", ctypes.c_int32)]
 
 
 class QeError(RuntimeError):
@@ -97,6 +103,13 @@ def lib():
     L.qe_quantconv2d_float_input_path.argtypes = [ctypes.POINTER(QeConvShape), ctypes.POINTER(QeQParam)]
     L.qe_quantize_pack.restype = i32
     L.qe_quantize_pack.argtypes = [vp, i64, vp, vp, i32, i64, ctypes.c_float, ctypes.c_float, i32, i32, vp, vp, vp]
+    pq, ps, pr = ctypes.POINTER(QeQParam), ctypes.POINTER(QeConvShape), ctypes.POINTER(QeRequant)
+    L.qe_quantconv2d_requant_path.restype = i32
+    L.qe_quantconv2d_requant_path.argtypes = [ps, pq, pq, pr]
+    L.qe_quantconv2d_requant_workspace_bytes.restype = sz
+    L.qe_quantconv2d_requant_workspace_bytes.argtypes = [ps, pq, pq, pr]
+    L.qe_quantconv2d_requant_prepared.restype = i32
+    L.qe_quantconv2d_requant_prepared.argtypes = [pq, pq, vp, ps, vp, sz, pr, vp, vp, vp, sz, vp]
     _lib = L
     return L
 
@@ -210,6 +223,37 @@ def quantconv2d_prepared(xq, wq, bias, sh, prepared, out=None, workspace=None, s
                                         out.data_ptr(), None if workspace is None else workspace.data_ptr(),
                                         0 if workspace is None else workspace.numel(), _stream(stream)))
     return out
+
+
+def requant(scale, zero, qmin, qmax, n_bits, sign):
+    """qe_requant: the consumer's activation quantiser (module convention: q = round(y / scale - zero).clamp(qmin, qmax))."""
+    r = QeRequant(scale.data_ptr(), zero.data_ptr(), int(scale.numel()), float(qmin), float(qmax), int(n_bits), 1 if sign else 0)
+    r._keep = (scale, zero)
+    return r
+
+
+def requant_path(sh, xq, wq, rq):
+    return int(lib().qe_quantconv2d_requant_path(ctypes.byref(sh), ctypes.byref(xq), ctypes.byref(wq), ctypes.byref(rq)))
+
+
+def quantconv2d_requant_prepared(xq, wq, bias, sh, prepared, rq, out=None, status=None, workspace=None, stream=None):
+    """qe_quantconv2d_requant_prepared: conv + the consumer's quantiser + tpack in one call; returns (packed uint8, status)."""
+    import torch
+    dev = wq._keep[0].device
+    OH, OW = out_hw(sh)
+    if out is None:
+        out = torch.empty(packed_nbytes(sh.N * sh.OC * OH * OW, rq.n_bits), dtype=torch.uint8, device=dev)
+    if status is None:
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+    need = int(lib().qe_quantconv2d_requant_workspace_bytes(ctypes.byref(sh), ctypes.byref(xq), ctypes.byref(wq), ctypes.byref(rq)))
+    if workspace is None and need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    check(lib().qe_quantconv2d_requant_prepared(ctypes.byref(xq), ctypes.byref(wq), None if bias is None else bias.data_ptr(),
+                                                ctypes.byref(sh), prepared.data_ptr() if prepared.numel() else None, prepared.numel(),
+                                                ctypes.byref(rq), out.data_ptr(), status.data_ptr(),
+                                                None if workspace is None else workspace.data_ptr(),
+                                                0 if workspace is None else workspace.numel(), _stream(stream)))
+    return out, status
 
 
 def quantize_pack(x, scale, zero, qmin, qmax, n_bits, sign, inner=1, out=None, status=None, stream=None):

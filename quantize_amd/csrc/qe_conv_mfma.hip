@@ -599,6 +599,20 @@ size_t mfma_conv_workspace_bytes(const qe_conv_shape *sh, int x_bits, int w_bits
     return p.ok ? p.total : 0;
 }
 
+// does this layer's kernel carry the fused re-quantisation epilogue (8-bit codes, per-tensor output scale)?
+bool mfma_conv_requant_fused(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w, int rq_bits, int rq_n_param)
+{
+    if (x->n_param != 1 || rq_bits != 8 || rq_n_param != 1) return false;
+    const MfmaPlan p = make_plan(sh, x->n_bits, w->n_bits);
+    if (!p.ok) return false;
+    if (p.flat || p.flatg) {
+        const qe_conv_shape ds = p.sub ? dense_shape(sh) : *sh;
+        const size_t patch = p.flatg ? (size_t)p.GI * p.MT * ds.H * ds.W : (size_t)p.MT * 32 * p.ni;
+        return align_up(p.lds, 16) + patch <= (size_t)MF_MAX_LDS;
+    }
+    return true;
+}
+
 // bytes of the x-independent part (re-laid-out weights, per-channel constants, tap-sum tables); 0: nothing to prepare
 size_t mfma_conv_prepared_bytes(const qe_conv_shape *sh, int x_bits, int w_bits)
 {
@@ -608,9 +622,11 @@ size_t mfma_conv_prepared_bytes(const qe_conv_shape *sh, int x_bits, int w_bits)
 
 // mode 0: prepare + run (workspace = [prepared part | scratch]); mode 1: prepare only into `prepared`;
 // mode 2: run on a `prepared` buffer filled earlier (workspace = scratch only)
+// rq != nullptr: fused re-quantisation -- the epilogues store 8-bit codes into rq->out instead of fp32 into `out`
+// (mode 0 or 2).  QE_ERR_UNSUPPORTED when this layer's kernel has no such epilogue (caller: conv + quantize_pack).
 int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh,
                      float *out, void *workspace, size_t workspace_bytes, hipStream_t s, int mode, void *prepared,
-                     size_t prepared_bytes)
+                     size_t prepared_bytes, const RequantHost *rq)
 {
     const MfmaPlan p = make_plan(sh, x->n_bits, w->n_bits);
     if (!p.ok) return QE_ERR_UNSUPPORTED;
@@ -679,7 +695,7 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
         const char *e = getenv("QE_FLATD");
         const int mask = e ? atoi(e) : QE_FLATD_DEFAULT;
         const int bit = var == 7 ? 1 : (var == 5 ? 2 : (var == 8 ? 4 : 0));
-        if (var != 0 && (mask & bit)) return mode == 1 ? QE_OK : launch_flatd(x, w, bias, sh, out, s);
+        if (var != 0 && (mask & bit) && rq == nullptr) return mode == 1 ? QE_OK : launch_flatd(x, w, bias, sh, out, s);
     }
 
     PrepArgs pa;
@@ -711,6 +727,15 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     a.GI = p.GI;
     a.PADW = p.ws ? p.PADW : sh->padding;
     a.dbg = g_mfma_dbg;
+    a.rq_out = nullptr; a.rq_scale = nullptr; a.rq_zero = nullptr; a.rq_status = nullptr;
+    a.rq_qmin = a.rq_qmax = a.rq_lo = a.rq_hi = 0.0f; a.rq_offset = 0;
+    if (rq != nullptr) {
+        if (rq->n_bits != 8 || rq->n_param != 1 || rq->out == nullptr) return QE_ERR_UNSUPPORTED;
+        a.rq_out = rq->out; a.rq_scale = rq->scale; a.rq_zero = rq->zero;
+        a.rq_qmin = rq->qmin; a.rq_qmax = rq->qmax; a.rq_status = rq->status;
+        a.rq_offset = rq->sign ? 128u : 0u;                       // tpack.cu:108-111
+        a.rq_lo = rq->sign ? -128.0f : 0.0f; a.rq_hi = rq->sign ? 127.0f : 255.0f;
+    }
     a.w_raw = w->data; a.w_scale = w->scale; a.w_zero = w->zero; a.x_scale = x->scale; a.bias = bias;
     a.w_bits = w->n_bits; a.w_sign = w->sign; a.w_per_tensor = (w->n_param == 1);
 
@@ -771,18 +796,26 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
         a.ctab = (a.ptab_off != 0 && a.n_top + a.n_bot < p.OH && a.n_lft + a.n_rgt < p.OW &&
                   ncls <= (sh->KH + 1) * (sh->KW + 1) && !(getenv("QE_CTAB") && atoi(getenv("QE_CTAB")) == 0)) ? 1 : 0;
     }
+    // flat kernels with fused re-quantisation: room for the workgroup's byte patch behind the staging image
+    size_t lds_f = p.lds;
+    if (rq != nullptr && (p.flat || p.flatg)) {
+        const size_t patch = p.flatg ? (size_t)p.GI * p.MT * sh->H * sh->W : (size_t)p.MT * 32 * p.ni;
+        a.ptab_off = (int)align_up(p.lds, 16);
+        lds_f = (size_t)a.ptab_off + patch;
+        if (lds_f > (size_t)MF_MAX_LDS) return QE_ERR_UNSUPPORTED;
+    }
     if (p.flatg) {
-        launch_mfma_flatg(a, p.NS, p.wraw, (unsigned)blocks, p.lds, s);
+        launch_mfma_flatg(a, p.NS, p.wraw, (unsigned)blocks, lds_f, s);
         QE_LAUNCH_CHECK();
         return QE_OK;
     }
     if (p.flat && p.x4) {
-        launch_mfma_flat_x4(a, p.niw, p.NS, (unsigned)blocks, p.lds, s);
+        launch_mfma_flat_x4(a, p.niw, p.NS, (unsigned)blocks, lds_f, s);
         QE_LAUNCH_CHECK();
         return QE_OK;
     }
     if (p.flat) {
-        launch_mfma_flat(a, p.cfg, p.niw, p.NS, p.wraw, p.s2, (unsigned)blocks, p.lds, s);
+        launch_mfma_flat(a, p.cfg, p.niw, p.NS, p.wraw, p.s2, (unsigned)blocks, lds_f, s);
         QE_LAUNCH_CHECK();
         return QE_OK;
     }

@@ -42,6 +42,79 @@ struct MfmaArgs {
     const uint8_t *w_raw;      // packed OIHW weights as the caller passed them
     const float *w_scale, *w_zero, *x_scale, *bias;
     int w_bits, w_sign, w_per_tensor;
+    // fused re-quantisation of the output (qe_quantconv2d_requant): rq_out != nullptr -> the epilogue stores the 8-bit
+    // code of round(y / scale - zero).clamp(qmin, qmax) (1 byte per element, NCHW) instead of the fp32 y into `out`
+    uint8_t *rq_out;
+    const float *rq_scale, *rq_zero;   // per tensor (the consumer's activation quantiser; its conv wants one scale anyway)
+    float rq_qmin, rq_qmax, rq_lo, rq_hi;   // clamp of the quantiser; representable range of the code (tpack's range test)
+    unsigned rq_offset;                     // stored code = (q + offset) & 0xff (tpack.cu:108-111)
+    int32_t *rq_status;                     // bit 0 set when a value fails the range test (NaN, or qmin/qmax outside the code range)
+};
+
+// y -> stored 8-bit code with the arithmetic of the fused quantise+pack kernel (qe_tpack.hip tp_quantize + tp_code):
+//   r = rint(y / scale - zero) ; clamp to [qmin, qmax] ; code = (int(r) + offset) & 0xff ; flag when r is NaN or outside the
+// code range.  An IEEE division per output element (~10 VALU instructions) made the fused epilogue SLOWER than storing fp32
+// (4.84 vs 4.17 ms per step), so the quotient comes from Markstein's sequence on a reciprocal taken once per thread:
+//   q0 = y * rcp ; e = fma(-scale, q0, y) ; q = fma(e, rcp, q0)
+// which IS the correctly rounded y / scale whenever rcp = RN(1 / scale), the significand of scale is not all ones and
+// nothing over- or underflows (Markstein 1990; Cornea et al., "Scientific computing on Itanium", thm. 8.3).  y is first
+// clamped to +-B with B / |scale| beyond the clamp bounds, which changes no code and keeps infinities out of the fma;
+// tiny quotients (where the sequence could round differently) cannot reach a rounding boundary of q - zero.  Scales
+// outside those conditions take the division (`slow`, uniform).  When the status flag comes back set the codes are
+// unspecified (the reference raises "out of range" there).
+struct RqConst {
+    float sc, rcp, nsc, zr, qmin, qmax, offf, B, lo, hi;
+    bool slow, chk;
+};
+__device__ __forceinline__ RqConst rq_setup(const MfmaArgs &a)
+{
+    RqConst c;
+    c.sc = a.rq_scale[0];
+    c.zr = a.rq_zero[0];
+    c.rcp = 1.0f / c.sc;
+    c.nsc = -c.sc;
+    c.qmin = a.rq_qmin; c.qmax = a.rq_qmax; c.lo = a.rq_lo; c.hi = a.rq_hi;
+    c.offf = (float)a.rq_offset;
+    const float asc = fabsf(c.sc);
+    const float span = fmaxf(fabsf(c.qmin), fabsf(c.qmax)) + fabsf(c.zr) + 2.0f;
+    c.B = asc * span * 2.0f;
+    c.slow = !(asc >= 0x1p-60f && asc <= 0x1p60f) || (__float_as_uint(c.sc) & 0x7fffffu) == 0x7fffffu || !(span <= 0x1p30f) ||
+             !(c.qmin <= c.qmax);
+    c.chk = !(c.qmin >= c.lo && c.qmax <= c.hi);          // clamp bounds inside the code range: only NaN can fail the range test
+    return c;
+}
+// returns r + offset as a float (0 .. 255 whenever the range test passes)
+__device__ __forceinline__ float rq_value(const RqConst &c, float v, bool &bad)
+{
+    float r;
+    if (c.slow) {
+        r = rintf(v / c.sc - c.zr);
+        r = (r != r) ? r : fminf(fmaxf(r, c.qmin), c.qmax);
+        bad |= !(r >= c.lo && r <= c.hi);
+    } else {
+        bad |= (v != v);
+        const float vc = __builtin_amdgcn_fmed3f(v, -c.B, c.B);
+        const float q0 = vc * c.rcp;
+        const float e = fmaf(c.nsc, q0, vc);
+        const float q = fmaf(e, c.rcp, q0);
+        r = __builtin_amdgcn_fmed3f(rintf(q - c.zr), c.qmin, c.qmax);
+        if (c.chk) bad |= !(r >= c.lo && r <= c.hi);
+    }
+    return r + c.offf;
+}
+__device__ __forceinline__ void rq_report(const MfmaArgs &a, bool bad)
+{
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0 && a.rq_status != nullptr) atomicOr(a.rq_status, 1);
+}
+
+// host-side description of a fused output quantiser (qe_requant of the C ABI + destination)
+struct RequantHost {
+    uint8_t *out;
+    const float *scale, *zero;
+    int n_param;
+    float qmin, qmax;
+    int n_bits, sign;
+    int32_t *status;
 };
 
 // stored code u -> MFMA operand a = q - d = u - c, c = off (signed) | 128 (unsigned 8-bit) | 0
@@ -128,12 +201,11 @@ struct TileGeom {
     int NT;      // valid columns (images that exist x OHWt)
 };
 
-template <int WM, int WN, int NIW>
-__device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW], const int (&sxs)[NIW],
-                                              const bool need_sx, const TileGeom g, const int ot,
-                                              const int wm, const int wn, const int col, const int h, const int KK,
-                                              const int *ptab = nullptr,   // LDS copy of this tile's rows of a.ws, or null
-                                              const float *ctab = nullptr) // LDS [border class][MT] correction table, or null
+template <int WM, int WN, int NIW, bool RQ>
+__device__ __forceinline__ void mfma_epilogue_impl(const MfmaArgs &a, v16i (&acc)[NIW], const int (&sxs)[NIW],
+                                                   const bool need_sx, const TileGeom g, const int ot,
+                                                   const int wm, const int wn, const int col, const int h, const int KK,
+                                                   const int *ptab, const float *ctab)
 {
     constexpr int MT = 32 * WM;
     const float zxp = a.x_zero[0] - zero_shift(a.x_bits, a.x_sign);
@@ -150,8 +222,13 @@ __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW
     const int OHW = a.OH * a.OW;
     const bool full_oc = (ot + 1) * MT <= a.OC;
     // wave-uniform base: image n0, first channel of the wave's 32-row strip, first row of the tile
-    float *out_w = a.out + ((int64_t)g.n0 * a.OC + ot * MT + wm * 32) * OHW + (int64_t)g.oh0 * a.OW;
-
+    const int64_t out_base = ((int64_t)g.n0 * a.OC + ot * MT + wm * 32) * OHW + (int64_t)g.oh0 * a.OW;
+    float *out_w = a.out + (RQ ? 0 : out_base);
+    // RQ: one byte per element (lanes 0-31 = 32 consecutive bytes of row dr, lanes 32-63 of row dr + 4)
+    uint8_t *out_q = RQ ? a.rq_out + out_base : nullptr;
+    bool bad = false;
+    RqConst rqc;
+    if constexpr (RQ) rqc = rq_setup(a);   // per tensor: wave-uniform constants, no registers per row
     // per-lane element offset of column q: image gi of the tile, pixel rq inside it, rows 4h apart
     uint32_t voff[NIW];
     bool valid[NIW];
@@ -164,6 +241,14 @@ __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW
         voff[t] = valid[t] ? (uint32_t)(gi * a.OC + 4 * h) * (uint32_t)OHW + (uint32_t)rq : 0u;
     }
 
+    // store of element (register r -> row dr, column slot t): fp32, or its 8-bit code (byte stores: lanes 0-31 = 32 consecutive
+    // bytes of row dr, lanes 32-63 of row dr + 4.  A per-wave LDS patch turned into 16-byte stores was tried: hipcc spilled
+    // 600-900 bytes per lane in EVERY kernel sharing this epilogue, the fp32 instances included; removed.)
+    auto emit = [&](int r, int dr, int t, float val) __attribute__((always_inline)) {
+        if constexpr (RQ) (out_q + (int64_t)dr * OHW)[voff[t]] = (uint8_t)(unsigned)rq_value(rqc, val, bad);
+        else (out_w + (int64_t)dr * OHW)[voff[t]] = val;
+    };
+
     if (!need_sx && !need_sw) {
         // symmetric operands: out = bias + alpha * S_aw.  Store address = wave-uniform row base
         // (scalar) + one per-lane 32-bit offset: lanes 0-31 are 32 consecutive pixels of row dr,
@@ -174,15 +259,13 @@ __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW
             if (full_oc && q0 + 32 <= g.NT) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float *row = out_w + (int64_t)((r & 3) + 8 * (r >> 2)) * OHW;  // uniform
-                    row[voff[t]] = fmaf(al[r], (float)acc[t][r], bi[r]);
+                    emit(r, (r & 3) + 8 * (r >> 2), t, fmaf(al[r], (float)acc[t][r], bi[r]));
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int dr = (r & 3) + 8 * (r >> 2);
-                    float *row = out_w + (int64_t)dr * OHW;
-                    if (valid[t] && oc_base + dr < a.OC) row[voff[t]] = fmaf(al[r], (float)acc[t][r], bi[r]);
+                    if (valid[t] && oc_base + dr < a.OC) emit(r, dr, t, fmaf(al[r], (float)acc[t][r], bi[r]));
                 }
             }
         }
@@ -218,7 +301,7 @@ __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW
                         const int dr = (r & 3) + 8 * (r >> 2);
                         float v = (float)acc[t][r] + ct[dr];
                         if (need_sx) v = fmaf(-zwc[r], (float)sxs[t], v);
-                        (out_w + (int64_t)dr * OHW)[voff[t]] = fmaf(al[r], v, bi[r]);
+                        emit(r, dr, t, fmaf(al[r], v, bi[r]));
                     }
                 } else {
 #pragma unroll
@@ -227,10 +310,11 @@ __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW
                         float v = (float)acc[t][r] + ct[dr];
                         if (need_sx) v = fmaf(-zwc[r], (float)sxs[t], v);
                         const float res = fmaf(al[r], v, bi[r]);
-                        if (valid[t] && oc_base + dr < a.OC) (out_w + (int64_t)dr * OHW)[voff[t]] = res;
+                        if (valid[t] && oc_base + dr < a.OC) emit(r, dr, t, res);
                     }
                 }
-            }
+                }
+            if constexpr (RQ) rq_report(a, bad);
             return;
         }
         float zw[16];
@@ -274,10 +358,22 @@ __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW
                     v = fmaf(fn * zxp, zw[r], v);
                 }
                 const float res = fmaf(al[r], v, bi[r]);
-                if (valid[t] && oc < a.OC) (out_w + (int64_t)dr * OHW)[voff[t]] = res;
+                if (valid[t] && oc < a.OC) emit(r, dr, t, res);
             }
         }
     }
+    if constexpr (RQ) rq_report(a, bad);
+}
+
+template <int WM, int WN, int NIW>
+__device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW], const int (&sxs)[NIW],
+                                              const bool need_sx, const TileGeom g, const int ot,
+                                              const int wm, const int wn, const int col, const int h, const int KK,
+                                              const int *ptab = nullptr,   // LDS copy of this tile's rows of a.ws, or null
+                                              const float *ctab = nullptr) // LDS [border class][MT] correction table, or null
+{
+    if (a.rq_out != nullptr) mfma_epilogue_impl<WM, WN, NIW, true>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab, ctab);
+    else mfma_epilogue_impl<WM, WN, NIW, false>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab, ctab);
 }
 
 // Asymmetric activations (zx' != 0): the border-aware S_w lookups of the epilogue go to an LDS copy of this tile's MT
@@ -1631,6 +1727,51 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
     // stores of full lines).  Each wave therefore turns its 32 oc x 32 px tile through a private LDS
     // patch (row stride 36 floats: conflict-free b128 writes) and reads it back with 8 lanes per
     // channel row: one global_store_dwordx4 then writes 8 rows x 128 contiguous bytes.
+    if (a.rq_out != nullptr) {
+        // Fused re-quantisation: 8-bit codes instead of fp32.  The workgroup's MT x NTP tile of codes goes through ONE byte
+        // patch in LDS (behind the staging image and the channel sums: a.ptab_off), then every thread stores 16-byte
+        // pieces of rows: NTP contiguous bytes per output channel instead of 4 x NTP.
+        uint8_t *bp = smem + a.ptab_off;                                       // [MT][NTP]
+        const RqConst rqc = rq_setup(a);
+        bool bad = false;
+#pragma unroll
+        for (int t = 0; t < NIW; ++t) {
+            const int q0 = (wn + t * WN) * 32;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                uint32_t pk = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float f = (float)acc[t][4 * gq + j] + cst;
+                    if (need_sx) f = fmaf(-zwp, (float)sxp[q0 + 8 * gq + 4 * h + j], f);
+                    pk = __builtin_amdgcn_cvt_pk_u8_f32(rq_value(rqc, fmaf(alpha, f, bia), bad), j, pk);
+                }
+                *reinterpret_cast<uint32_t *>(bp + (wm * 32 + col) * NTP + q0 + 8 * gq + 4 * h) = pk;
+            }
+        }
+        // lanes of channel rows >= OC and pixels >= NT computed on padding: their codes are never stored, their range flags dropped
+        if (oc >= a.OC) bad = false;
+        __syncthreads();
+        constexpr int PPR = NTP / 16;                                          // 16-byte pieces per row
+        for (int e = tid; e < MT * PPR; e += MF_THREADS) {
+            const int row = e / PPR, px = 16 * (e - row * PPR);
+            const int oc_r = ot * MT + row;
+            if (oc_r < a.OC && px < NT) {
+                const uint4 d4 = *reinterpret_cast<const uint4 *>(bp + row * NTP + px);
+                uint8_t *dst = a.rq_out + ((int64_t)n * a.OC + oc_r) * P + p0 + px;
+                if (px + 16 <= NT) {
+                    __builtin_memcpy(dst, &d4, 16);                            // dword aligned (P % 4 == 0)
+                } else {                                                       // NT % 4 == 0: whole dwords
+                    const uint32_t dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (px + 4 * k < NT) __builtin_memcpy(dst + 4 * k, &dd[k], 4);
+                }
+            }
+        }
+        rq_report(a, bad);
+        return;
+    }
     float *out_w = a.out + ((int64_t)n * a.OC + ot * MT + wm * 32) * P + p0;   // wave-uniform
     float *patch = reinterpret_cast<float *>(smem) + wave * (32 * 36);         // staging LDS is free now
     const int rrow = lane >> 3, rq = lane & 7;                                 // read-back: row within 8, pixel quad
@@ -1851,6 +1992,49 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flatg_kernel(const Mf
     // ---- epilogue: lane = output channel, 4 consecutive registers = 4 consecutive slots; per-wave LDS patch ----
     const int sw_sum = swacc + __shfl_xor(swacc, 32);
     const float cst = fmaf((float)a.IC * zxp, zwp, -zxp * (float)sw_sum);
+    if (a.rq_out != nullptr) {
+        // Fused re-quantisation (see conv_mfma_flat_kernel).  Byte patch in OUTPUT order [image gi][oc row][P]: the MT planes
+        // of one image are one contiguous run of MT * P bytes of the output tensor, stored as 16-byte pieces at byte alignment
+        // (49-byte planes; unaligned global_store_dwordx4: tools/probe_unaligned.hip).
+        uint8_t *bp = smem + a.ptab_off;
+        const RqConst rqc = rq_setup(a);
+        bool bad = false;
+#pragma unroll
+        for (int t = 0; t < NIW; ++t) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int m = t * 32 + 8 * gq + 4 * h;          // 4 consecutive slots: image gi, pixels p .. p + 3
+                const int gi = m / PS, p = m - gi * PS;
+                uint8_t *dst = bp + ((gi < GI ? gi : 0) * MT + wm * 32 + col) * P + p;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float f = (float)acc[t][4 * gq + j] + cst;
+                    if (need_sx) f = fmaf(-zwp, (float)sxp[m + j], f);
+                    bool b1 = false;
+                    const unsigned c = (unsigned)rq_value(rqc, fmaf(alpha, f, bia), b1);
+                    if (gi < GI && p + j < P) { dst[j] = (uint8_t)c; bad |= b1 && oc < a.OC && n0 + gi < a.N; }
+                }
+            }
+        }
+        __syncthreads();
+        const int rows = min(MT, a.OC - ot * MT);           // channel rows of this tile that exist
+        const int run = rows * P;                           // bytes per image
+        const int ppi = (run + 15) >> 4;                    // 16-byte pieces per image
+        for (int e = tid; e < GI * ppi; e += MF_THREADS) {
+            const int gi = e / ppi, b = 16 * (e - gi * ppi);
+            if (n0 + gi >= a.N) continue;
+            const uint8_t *src = bp + gi * MT * P + b;
+            uint8_t *dst = a.rq_out + ((int64_t)(n0 + gi) * a.OC + ot * MT) * P + b;
+            if (b + 16 <= run) {
+                const uint4 d4 = *reinterpret_cast<const uint4 *>(src);   // LDS side is 16-byte aligned (MT * P % 16 == 0)
+                __builtin_memcpy(dst, &d4, 16);
+            } else {
+                for (int k = 0; b + k < run; ++k) dst[k] = src[k];
+            }
+        }
+        rq_report(a, bad);
+        return;
+    }
     float *patch = reinterpret_cast<float *>(smem) + wave * (32 * 36);
     const int rrow = lane >> 3, rq = lane & 7;
     const int row_oc = ot * MT + wm * 32;               // first output channel of this wave's strip
