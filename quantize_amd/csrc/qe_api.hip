@@ -42,6 +42,15 @@ static int check_shape(const qe_conv_shape *sh)
     return QE_OK;
 }
 
+// scale / zero arrays: one element, or one per channel (IC for activations, OC for weights) -- anything else would be
+// indexed out of bounds by channel (the reference reads scale[ic] / scale[oc] unchecked, quantconv2d.cu:112-127)
+static int check_nparam(const qe_qparam *x, const qe_qparam *w, const qe_conv_shape *sh)
+{
+    if (x != nullptr && !(x->n_param == 1 || x->n_param >= sh->IC)) return QE_ERR_ARG;
+    if (!(w->n_param == 1 || w->n_param >= sh->OC)) return QE_ERR_ARG;
+    return QE_OK;
+}
+
 static int check_qparam(const qe_qparam *q)
 {
     if (q == nullptr || q->data == nullptr || q->scale == nullptr || q->zero == nullptr) return QE_ERR_ARG;
@@ -92,6 +101,7 @@ extern "C" int qe_quantconv2d(const qe_qparam *x, const qe_qparam *w, const floa
     if (rc != QE_OK) return rc;
     if ((rc = check_qparam(x)) != QE_OK) return rc;
     if ((rc = check_qparam(w)) != QE_OK) return rc;
+    if ((rc = check_nparam(x, w, shape)) != QE_OK) return rc;
     if (out == nullptr) return QE_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (mfma_conv_eligible(shape, x, w))
@@ -118,6 +128,7 @@ extern "C" int qe_conv_prepare(const qe_qparam *w, const float *bias, const qe_c
     int rc = check_shape(shape);
     if (rc != QE_OK) return rc;
     if ((rc = check_qparam(w)) != QE_OK) return rc;
+    if ((rc = check_nparam(nullptr, w, shape)) != QE_OK) return rc;
     if (!(x_bits > 0 && x_bits <= 8)) return QE_ERR_NBITS;
     if (mfma_conv_prepared_bytes(shape, x_bits, w->n_bits) == 0) return QE_OK;     // nothing to prepare for this problem
     qe_qparam x = *w;                      // only n_bits / n_param of the activations select the plan
@@ -134,6 +145,7 @@ extern "C" int qe_quantconv2d_prepared(const qe_qparam *x, const qe_qparam *w, c
     if (rc != QE_OK) return rc;
     if ((rc = check_qparam(x)) != QE_OK) return rc;
     if ((rc = check_qparam(w)) != QE_OK) return rc;
+    if ((rc = check_nparam(x, w, shape)) != QE_OK) return rc;
     if (out == nullptr) return QE_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (mfma_conv_eligible(shape, x, w))
@@ -181,6 +193,7 @@ extern "C" int qe_quantconv2d_requant_prepared(const qe_qparam *x, const qe_qpar
     if (rc != QE_OK) return rc;
     if ((rc = check_qparam(x)) != QE_OK) return rc;
     if ((rc = check_qparam(w)) != QE_OK) return rc;
+    if ((rc = check_nparam(x, w, shape)) != QE_OK) return rc;
     if ((rc = check_requant(rq)) != QE_OK) return rc;
     if (out == nullptr) return QE_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -212,6 +225,7 @@ extern "C" int qe_quantconv2d_float_input(const float *x, const qe_qparam *w, co
     int rc = check_shape(shape);
     if (rc != QE_OK) return rc;
     if ((rc = check_qparam(w)) != QE_OK) return rc;
+    if ((rc = check_nparam(nullptr, w, shape)) != QE_OK) return rc;
     if (x == nullptr || out == nullptr) return QE_ERR_ARG;
     return launch_conv_generic(false, x, nullptr, w, bias, shape, out, static_cast<hipStream_t>(stream));
 }
@@ -237,6 +251,7 @@ extern "C" int qe_quantconv2d_float_input_ws(const float *x, const qe_qparam *w,
     int rc = check_shape(shape);
     if (rc != QE_OK) return rc;
     if ((rc = check_qparam(w)) != QE_OK) return rc;
+    if ((rc = check_nparam(nullptr, w, shape)) != QE_OK) return rc;
     if (x == nullptr || out == nullptr) return QE_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (f32_conv_eligible(shape, w)) return launch_conv_f32(x, w, bias, shape, out, workspace, workspace_bytes, s, 0);
@@ -250,6 +265,7 @@ extern "C" int qe_conv_f32_prepare(const qe_qparam *w, const float *bias, const 
     int rc = check_shape(shape);
     if (rc != QE_OK) return rc;
     if ((rc = check_qparam(w)) != QE_OK) return rc;
+    if ((rc = check_nparam(nullptr, w, shape)) != QE_OK) return rc;
     if (!f32_conv_eligible(shape, w)) return QE_OK;          // nothing to prepare: the VALU kernel reads the packed weights
     return launch_conv_f32(nullptr, w, bias, shape, nullptr, prepared, prepared_bytes, static_cast<hipStream_t>(stream), 1);
 }
@@ -262,6 +278,7 @@ extern "C" int qe_quantconv2d_float_input_prepared(const float *x, const qe_qpar
     int rc = check_shape(shape);
     if (rc != QE_OK) return rc;
     if ((rc = check_qparam(w)) != QE_OK) return rc;
+    if ((rc = check_nparam(nullptr, w, shape)) != QE_OK) return rc;
     if (x == nullptr || out == nullptr) return QE_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (f32_conv_eligible(shape, w))

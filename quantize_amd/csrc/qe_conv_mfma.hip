@@ -220,6 +220,9 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits, bool
     p.KK = sh->KH * sh->KW;
     if (p.OH <= 0 || p.OW <= 0 || sh->N <= 0 || sh->OC <= 0) return p;
     if ((int64_t)sh->IC * sh->H * sh->W >= (1ll << 31)) return p;
+    // int32 accumulators: |a_x a_w| <= 2^14 per product, so a reduction of 2^17 or more terms could overflow silently where
+    // the reference (fp32 accumulation, quantconv2d.cu:84) merely rounds -> those problems keep the order-preserving fp32 kernel
+    if ((int64_t)sh->IC * sh->KH * sh->KW >= (1ll << 17)) return p;
     if ((int64_t)sh->N * sh->IC * sh->H * sh->W < 64) return p;  // clamped 8-byte reads need a stream >= 8 bytes
     if (sh->W < 4) return p;                                       // rows are fetched in 4-pixel quads
     if ((int64_t)sh->OC * p.OH * p.OW >= (1ll << 29)) return p;      // 32-bit store offsets inside one image

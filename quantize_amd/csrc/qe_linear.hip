@@ -370,7 +370,8 @@ static int check_lin_q(const qe_qparam *q, int64_t n_expected)
 
 static bool lin_mfma_eligible(const qe_qparam *x, const qe_qparam *w, int64_t B, int K, int O)
 {
-    return x->n_bits == 8 && w->n_bits == 8 && (K % LK) == 0 && K >= LK && B > 0 && O > 0 &&
+    // K < 2^17: int32 accumulation of products up to 2^14 cannot overflow (deeper reductions take the fp32 kernel, as the reference's fp32 sum does)
+    return x->n_bits == 8 && w->n_bits == 8 && (K % LK) == 0 && K >= LK && K < (1 << 17) && B > 0 && O > 0 &&
            (reinterpret_cast<uintptr_t>(x->data) & 15) == 0 && (reinterpret_cast<uintptr_t>(w->data) & 15) == 0;
 }
 

@@ -96,6 +96,35 @@ class PackedConv2d(_PackedBase):
         raise ValueError("route must be 'packed' or 'float'")
 
 
+    # ---- packed in, packed out: the conv-epilogue form of f-2 ----
+    def call_packed(self, xq, x_des, consumer=None):
+        """Activations as (packed stream, des) -- what quantize() or an earlier call_packed() returned.
+        consumer=None: the fp32 output.  consumer = the Packed* layer that reads this layer's output directly: returns the
+        (packed, des) pair of ITS activation quantiser, written by this layer's conv kernel itself
+        (qe_quantconv2d_requant_prepared): no fp32 tensor between the two layers.  Bit-identical to
+        consumer.quantize(self.call_packed(xq, x_des)).  (A ReLU in between folds into the clamp when the consumer's codes
+        are unsigned with zero point 0: round(max(y, 0) / s).clamp(0, qmax) == round(y / s).clamp(0, qmax).)"""
+        from . import capi
+        d = [int(v) for v in x_des.tolist()]
+        n_bits, sign, (N, IC, H, W) = d[0], d[1], d[2:6]
+        wd = [int(v) for v in self.w_des.tolist()]
+        sh = capi.conv_shape(N, IC, H, W, wd[2], wd[4], wd[5], self.stride, self.padding)
+        x = capi.qparam(xq, n_bits, sign, self.a_scale, self._neg_a_zero)
+        w = capi.qparam(self.weight, wd[0], wd[1], self.w_scale.reshape(-1), self._neg_w_zero.reshape(-1))
+        key = (n_bits, N, H, W)
+        if getattr(self, "_prep_key", None) != key:      # weights prepared once per problem shape
+            self._prepared, self._prep_key = capi.conv_prepare(w, self.bias, sh, n_bits), key
+        if consumer is None:
+            return capi.quantconv2d_prepared(x, w, self.bias, sh, self._prepared)
+        rq = capi.requant(consumer.a_scale, consumer.a_zero, consumer.a_qmin, consumer.a_qmax, consumer.a_bits, consumer.a_signed)
+        out, status = capi.quantconv2d_requant_prepared(x, w, self.bias, sh, self._prepared, rq)
+        if int(status.item()) != 0:
+            raise RuntimeError("The input tensor is out of range.")     # tpack.cu:14, as engine.tpack raises it
+        OH, OW = capi.out_hw(sh)
+        des = torch.tensor([consumer.a_bits, 1 if consumer.a_signed else 0, N, sh.OC, OH, OW], dtype=torch.int32, device=xq.device)
+        return out, des
+
+
 class PackedLinear(_PackedBase):
     """A packed QuantLinear's forward on the engine (quantlinear.py:150-161).  The packed x packed kernel of the
     reference indexes the activation scale by batch ROW (quantlinear.cu:96), so a per-tensor scale is what the modules'

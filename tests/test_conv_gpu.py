@@ -406,3 +406,21 @@ def test_batch_independence_every_kernel_family(engine):
             y1 = engine.quantconv2d(xp1, xd1, sx, z1, wp, wd, sw, zc, bias, s, p)
             assert torch.equal(y[n:n + 1], y1), (IC, OC, K, s, H, n)
         del qx, y, xp
+
+
+def test_scale_arrays_must_match_channels_and_deep_reductions_leave_mfma(engine):
+    """n_param that is neither 1 nor >= the channel count is an argument error (it would be indexed out of bounds); a
+    reduction of 2^17 or more terms keeps the fp32 kernel (int32 accumulators could overflow where the reference rounds)."""
+    dev = torch.device("cuda")
+    sh = capi.conv_shape(1, 8, 6, 6, 6, 3, 3, 1, 1)
+    xp = torch.zeros(8 * 36, dtype=torch.uint8, device=dev)
+    wp = torch.zeros(6 * 8 * 9, dtype=torch.uint8, device=dev)
+    one = torch.ones(1, device=dev)
+    three = torch.ones(3, device=dev)
+    with pytest.raises(capi.QeError, match="invalid argument"):
+        capi.quantconv2d(capi.qparam(xp, 8, True, three, three), capi.qparam(wp, 8, True, one, one), None, sh)
+    with pytest.raises(capi.QeError, match="invalid argument"):
+        capi.quantconv2d(capi.qparam(xp, 8, True, one, one), capi.qparam(wp, 8, True, three, three), None, sh)
+    xq, wq = capi.qparam(xp, 8, True, one, one), capi.qparam(wp, 8, True, one, one)
+    assert capi.conv_path(capi.conv_shape(1, 2048, 8, 8, 8, 7, 7, 1, 3), xq, wq) == 1      # 100352 terms
+    assert capi.conv_path(capi.conv_shape(1, 4096, 8, 8, 8, 7, 7, 1, 3), xq, wq) == 0      # 200704 terms >= 2^17

@@ -205,3 +205,14 @@ def test_error_messages(engine):
     s0 = torch.tensor(0.5, device=DEV)
     y = engine.quantlinear(xp, xd, s0, 0 * s0, wp, wd, s0, 0 * s0, torch.ones(3, device=DEV))
     assert tuple(y.shape) == (2, 3) and torch.equal(y, torch.ones(2, 3, device=DEV))
+
+
+def test_deep_reductions_leave_the_int32_kernel():
+    """K >= 2^17 products of up to 2^14 each could overflow the MFMA kernel's int32 accumulators: those problems keep the
+    fp32 kernel (the reference accumulates in fp32, quantlinear.cu:96-127)."""
+    dev = torch.device("cuda")
+    one = torch.ones(1, device=dev)
+    buf = torch.zeros(4 * (1 << 17), dtype=torch.uint8, device=dev)
+    xq, wq = capi.qparam(buf, 8, True, one, one), capi.qparam(buf, 8, True, one, one)
+    assert capi.linear_path(xq, wq, 4, (1 << 17) - 64, 4) == 1
+    assert capi.linear_path(xq, wq, 4, 1 << 17, 4) == 0

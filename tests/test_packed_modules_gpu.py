@@ -63,3 +63,43 @@ def test_packed_linear_on_reference_captures(g6):
         # leading dimensions (tokens) are flattened and restored
         y3 = m(x.reshape(3, 4, -1), route="packed")
         assert tuple(y3.shape) == (3, 4, ref.shape[1]) and np.abs(y3.reshape(12, -1).cpu().numpy() - ref).max() <= tol
+
+
+def _synthetic_state(rng, IC, OC, K, a_signed):
+    """A packed QuantConv2d's state_dict entries (quantconv2d.py:187-192) with random codes and per-channel weight scales."""
+    import quantize_amd.engine as engine
+    qw = torch.from_numpy(rng.randint(-128, 128, size=(OC, IC, K, K)).astype(np.int8)).to(DEV)
+    wp, wd = engine.tpack(qw, 8, True)
+    qmin, qmax = (-128.0, 127.0) if a_signed else (0.0, 255.0)
+    return {"weight": wp, "w_des": wd, "w_scale": _t(rng.uniform(1e-3, 3e-3, size=(OC, 1, 1, 1)).astype(np.float32)),
+            "w_zero": _t(np.zeros((OC, 1, 1, 1), np.float32)), "bias": _t(rng.normal(0, 0.1, size=OC).astype(np.float32)),
+            "a_quantizer.scale": _t(np.array([0.02 if a_signed else 0.011], np.float32)),
+            "a_quantizer.zero": _t(np.array([0.0], np.float32)),
+            "a_quantizer.qmin": torch.tensor(qmin), "a_quantizer.qmax": torch.tensor(qmax)}
+
+
+def test_packed_layers_chain_without_fp32_in_between():
+    """Three packed convs chained: each layer's conv kernel writes the NEXT layer's activation codes (fused
+    re-quantisation) -- same final output, bit for bit, as quantising every fp32 intermediate with the consumer's
+    quantizer (quantize_pack), which test_packed_conv2d_on_reference_captures pins to the reference module."""
+    rng = np.random.RandomState(11)
+    a = PackedConv2d.from_state_dict(_synthetic_state(rng, 64, 128, 1, True), stride=1, padding=0)
+    b = PackedConv2d.from_state_dict(_synthetic_state(rng, 128, 128, 3, False), stride=1, padding=1)    # unsigned: ReLU folded
+    c = PackedConv2d.from_state_dict(_synthetic_state(rng, 128, 256, 1, True), stride=2, padding=0)
+    # the consumers' scales must suit what arrives: calibrate them from one fp32 pass
+    x = torch.randn(4, 64, 28, 28, device=DEV)
+    xq, xd = a.quantize(x)
+    ya = a.call_packed(xq, xd)
+    b.a_scale = (ya.clamp(min=0).max() / 255.0).reshape(1)
+    yb = b.call_packed(*b.quantize(ya))
+    c.a_scale = (yb.abs().max() / 127.0).reshape(1)
+    ref = c.call_packed(*c.quantize(yb))
+    # fused chain
+    qb, db = a.call_packed(xq, xd, consumer=b)
+    qb_ref, db_ref = b.quantize(ya)
+    assert torch.equal(qb, qb_ref) and torch.equal(db.cpu(), db_ref.cpu())
+    qc, dc = b.call_packed(qb, db, consumer=c)
+    out = c.call_packed(qc, dc)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert tuple(out.shape) == (4, 256, 14, 14)
