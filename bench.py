@@ -462,7 +462,7 @@ def main():
                        "layers": n_launch, "kernel_paths": {"mfma": sum(L.path for L in layers),
                                                             "generic": sum(1 - L.path for L in layers)}},
             "roofline": {"bound": "hbm",
-                         "kernel": ("conv_f32_mfma_kernel (bf16 x3 MFMA; the 3-channel stem on conv_generic_kernel), 53 launches per step, one per layer"
+                         "kernel": ("conv_f32_mfma_kernel + conv_f32_stem_kernel (bf16 x3 MFMA), 53 launches per step, one per layer"
                                     if args.float_input else
                                     "conv_mfma_{flat,flatg,sm2,ws,smallic,}_kernel + conv_flatd_kernel: one launch per layer, 53 per step (the event span "
                                     "also holds the 2 gather launches of the strided 1x1 layers%s)"

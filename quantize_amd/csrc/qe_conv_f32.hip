@@ -358,6 +358,233 @@ __global__ __launch_bounds__(F32_THREADS, 2) void conv_f32_mfma_kernel(const F32
 }
 
 // ---------------------------------------------------------------------------------------------
+// Small-IC variant (IC <= 4, KH, KW <= 8): the stem (3 -> 64, 7x7 / 2).  Padding 3 channels to a 16-channel k-step
+// would waste 5x the MFMA work and the halo image of a 224-wide row band would not fit the LDS, so K is laid out as in the
+// packed stem kernel (conv_mfma_smallic_kernel): per kernel row kh, K = [kw 0..7][ic 0..3] = two 16-deep k-steps.  LDS
+// holds, per split, one 8-byte vector [x_ic0 x_ic1 x_ic2 0] (bf16) per halo pixel; the B fragment of lane (pixel, half h)
+// for k-step j is the 16 bytes of the 2 consecutive pixels at column ow*stride + 4j + 2h of row oh*stride + kh.
+//   Wt layout here: [KH * 2][1][OCP][16]: element 8h + 4 kwl + ic of "tap" 2 kh + j = q_w[oc][ic][kh][4j + 2h + kwl].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void conv_f32_prep_stem_kernel(const F32PrepArgs a, int KH, int KW)
+{
+    const int oc = blockIdx.x, tid = threadIdx.x;
+    const bool live = oc < a.OC;
+    const int off = a.w_sign ? (1 << (a.w_bits - 1)) : 0;
+    for (int idx = tid; idx < KH * 2; idx += 64) {
+        const int kh = idx >> 1, j = idx & 1;
+        uint32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (live) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int hh = e >> 3, kwl = (e >> 2) & 1, ic = e & 3;
+                const int kw = 4 * j + 2 * hh + kwl;
+                if (kw < KW && ic < a.IC) {
+                    const int q = f32_unpack_code(a.w, (((int64_t)oc * a.IC + ic) * KH + kh) * KW + kw, a.w_bits) - off;
+                    v[e >> 1] |= (__float_as_uint((float)q) >> 16) << (16 * (e & 1));
+                }
+            }
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(a.wt + ((int64_t)idx * a.OCP + oc) * 16);
+        dst[0] = make_uint4(v[0], v[1], v[2], v[3]);
+        dst[1] = make_uint4(v[4], v[5], v[6], v[7]);
+    }
+    if (tid == 0) {
+        float sw = 0.0f, zw = 0.0f, b = 0.0f;
+        if (live) {
+            sw = a.w_per_tensor ? a.w_scale[0] : a.w_scale[oc];
+            zw = a.w_per_tensor ? a.w_zero[0] : a.w_zero[oc];
+            b = a.bias ? a.bias[oc] : 0.0f;
+        }
+        a.ep[oc] = sw;
+        a.ep[a.OCP + oc] = zw;
+        a.ep[2 * a.OCP + oc] = b;
+    }
+}
+
+template <int WM, int WN, int NIW>
+__global__ __launch_bounds__(F32_THREADS, 2) void conv_f32_stem_kernel(const F32Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint2 *Xs = reinterpret_cast<uint2 *>(smem);                 // [3 splits][GSZ] (+ trash)
+    constexpr int MT = 32 * WM;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int col = lane & 31, h = lane >> 5;
+
+    int pt, ot;
+    {
+        const int bid = blockIdx.x, idx = bid >> 3;
+        const int j = idx / a.n_oc_tiles;
+        ot = idx - j * a.n_oc_tiles;
+        const int c = j / a.chunk;
+        pt = (c * 8 + (bid & 7)) * a.chunk + (j - c * a.chunk);
+    }
+    if (pt >= a.n_pix_tiles) return;
+    const int n0 = pt / a.tiles_h;
+    const int oh0 = (pt - n0 * a.tiles_h) * a.TH;
+    const int th = min(a.TH, a.OH - oh0);
+    const int NT = th * a.OW;
+    const int ih0 = oh0 * a.stride - a.pad;
+    const int GSZ = a.IHT * a.IWP;
+    const int trash = 3 * GSZ + lane;
+    float *sxp = reinterpret_cast<float *>(Xs + 3 * GSZ + F32_TRASH);           // [GSZ] channel sums per halo pixel
+
+    for (int i = tid; i < 3 * GSZ; i += F32_THREADS) Xs[i] = make_uint2(0, 0);
+    for (int i = tid; i < GSZ; i += F32_THREADS) sxp[i] = 0.0f;
+
+    int zw_local = 0;
+    if (tid < MT) zw_local = (a.ep[a.OCP + ot * MT + tid] != 0.0f) ? 1 : 0;
+    const bool need_sx = __syncthreads_or(zw_local) != 0;      // also orders the LDS zero fill
+
+    // weight fragments of all kernel rows (L2 hits), requested before the activation loads
+    v4i afr[8][2];
+    {
+        const uint16_t *a_base = a.wt + ((int64_t)(ot * MT + wm * 32 + col) * 16 + 8 * h);
+#pragma unroll
+        for (int kh = 0; kh < 8; ++kh) {
+            const int khc = kh < a.KH ? kh : a.KH - 1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) afr[kh][j] = *reinterpret_cast<const v4i *>(a_base + (int64_t)(khc * 2 + j) * a.OCP * 16);
+        }
+    }
+
+    // ---- stage the halo tile: thread <-> (row l, column quad iq): IC 16-byte loads, 4 pixels x 3 splits x 8 bytes ----
+    const int NQ = (a.W + 3) >> 2;
+    const int HW = a.H * a.W;
+    const float *xi = a.x + (int64_t)n0 * a.IC * HW;
+    const int n_units = a.IHT * NQ;
+    for (int u0 = 0; u0 < n_units; u0 += 2 * F32_THREADS) {
+        float4 d[2][4];
+        int ul[2], uq[2], ues[2];
+        bool uok[2], ulive[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int uid = u0 + tid + it * F32_THREADS;
+            ulive[it] = uid < n_units;
+            const int uc = ulive[it] ? uid : 0;
+            const int l = uc / NQ, iq = uc - l * NQ;
+            const int ih = ih0 + l;
+            const bool ok = ih >= 0 && ih < a.H;
+            int iw0 = 4 * iq, es = 0;
+            if (iw0 + 4 > a.W) { es = iw0 + 4 - a.W; iw0 = a.W - 4; }          // never read past the row: shifted back
+            const uint32_t off = ok ? (uint32_t)(ih * a.W + iw0) : 0u;
+            ul[it] = l; uq[it] = iq; ues[it] = es; uok[it] = ok;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int icc = i < a.IC ? i : a.IC - 1;       // uniform
+                __builtin_memcpy(&d[it][i], xi + (int64_t)icc * HW + off, 16);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            float xr[4][4];                                    // [channel][pixel of the quad]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool pad_ch = i >= a.IC;
+                const float e0 = pad_ch ? 0.0f : d[it][i].x, e1 = pad_ch ? 0.0f : d[it][i].y, e2 = pad_ch ? 0.0f : d[it][i].z, e3 = pad_ch ? 0.0f : d[it][i].w;
+                const int es = ues[it];
+                xr[i][0] = es == 0 ? e0 : (es == 1 ? e1 : (es == 2 ? e2 : e3));
+                xr[i][1] = es == 0 ? e1 : (es == 1 ? e2 : e3);
+                xr[i][2] = es == 0 ? e2 : e3;
+                xr[i][3] = e3;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iw = 4 * uq[it] + j;
+                const int cl = iw + a.pad;
+                const bool pok = ulive[it] && uok[it] && iw < a.W && cl < a.IWP;
+                const int idx = pok ? ul[it] * a.IWP + cl : -1;
+                float x[4] = {xr[0][j], xr[1][j], xr[2][j], xr[3][j]};
+                if (need_sx && pok) sxp[idx] = ((x[0] + x[1]) + x[2]) + x[3];
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) {
+                    uint32_t u[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        u[i] = __float_as_uint(x[i]) & 0xffff0000u;           // sp == 2: the remainder has <= 8 significant bits
+                        x[i] -= __uint_as_float(u[i]);
+                    }
+                    Xs[pok ? idx + sp * GSZ : trash] =
+                        make_uint2(__builtin_amdgcn_perm(u[1], u[0], 0x07060302u), __builtin_amdgcn_perm(u[3], u[2], 0x07060302u));
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    int pixidx[NIW];
+#pragma unroll
+    for (int t = 0; t < NIW; ++t) {
+        const int q = (wn + t * WN) * 32 + col;
+        const int r = q / a.OW, c = q - r * a.OW;
+        pixidx[t] = (q < NT) ? (r * a.stride) * a.IWP + c * a.stride : 0;
+    }
+    v16f acc[NIW];
+#pragma unroll
+    for (int t = 0; t < NIW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+#pragma unroll
+    for (int kh = 0; kh < 8; ++kh) {
+        if (kh < a.KH) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const v8bf wf = __builtin_bit_cast(v8bf, afr[kh][j]);
+#pragma unroll
+                for (int t = 0; t < NIW; ++t) {
+                    const uint2 *bp = &Xs[pixidx[t] + kh * a.IWP + 4 * j + 2 * h];
+#pragma unroll
+                    for (int sp = 2; sp >= 0; --sp) {                            // smallest parts first
+                        const uint2 b0 = bp[sp * GSZ], b1 = bp[sp * GSZ + 1];
+                        const v4i b = {(int)b0.x, (int)b0.y, (int)b1.x, (int)b1.y};
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(v8bf, b), acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue (as conv_f32_mfma_kernel) ----
+    float sxs[NIW];
+#pragma unroll
+    for (int t = 0; t < NIW; ++t) {
+        sxs[t] = 0.0f;
+        if (need_sx) {
+            for (int kh = 0; kh < a.KH; ++kh)
+                for (int kw = 0; kw < a.KW; ++kw) sxs[t] += sxp[pixidx[t] + kh * a.IWP + kw];     // zero outside the image
+        }
+    }
+    const int oc_base = ot * MT + wm * 32 + 4 * h;
+    float sw[16], zw[16], bi[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int oc = oc_base + (r & 3) + 8 * (r >> 2);
+        sw[r] = a.ep[oc];
+        zw[r] = a.ep[a.OCP + oc];
+        bi[r] = a.ep[2 * a.OCP + oc];
+    }
+    const int OHW = a.OH * a.OW;
+    const bool full_oc = (ot + 1) * MT <= a.OC;
+    float *out_w = a.out + ((int64_t)n0 * a.OC + ot * MT + wm * 32) * OHW + (int64_t)oh0 * a.OW;
+#pragma unroll
+    for (int t = 0; t < NIW; ++t) {
+        const int q = (wn + t * WN) * 32 + col;
+        const bool valid = q < NT;
+        const uint32_t voff = valid ? (uint32_t)(4 * h) * (uint32_t)OHW + (uint32_t)q : 0u;
+        const bool whole = full_oc && (wn + t * WN) * 32 + 32 <= NT;            // wave-uniform: plain stores
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            float v = acc[t][r];
+            if (need_sx) v = fmaf(-zw[r], sxs[t], v);
+            const float res = fmaf(sw[r], v, bi[r]);
+            if (whole || (valid && oc_base + dr < a.OC)) (out_w + (int64_t)dr * OHW)[voff] = res;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 struct F32Plan {
@@ -365,6 +592,8 @@ struct F32Plan {
     int cfg = 0;               // 0: 4x1 waves x 7 column tiles (MT 128), 1: 2x2 x 4 (MT 64)
     int MT = 0, OCP = 0, NG = 0, KK = 0, OH = 0, OW = 0;
     int TH = 0, GI = 1, IHT = 0, IWP = 0, ROWMUL = 1, COLMUL = 1, NS = 1;
+    bool stem = false;         // IC <= 4: K = kh x [kw 0..7][ic 0..3] (conv_f32_stem_kernel)
+    int niw = 0;
     size_t lds = 0, wt_bytes = 0, ep_off = 0, total = 0;
 };
 
@@ -378,7 +607,33 @@ static F32Plan f32_plan(const qe_conv_shape *sh)
     p.OW = (sh->W + 2 * sh->padding - sh->KW) / sh->stride + 1;
     p.KK = sh->KH * sh->KW;
     if (p.OH <= 0 || p.OW <= 0 || sh->N <= 0 || sh->OC <= 0) return p;
-    if (sh->W < 4 || p.KK > 64 || sh->IC < 8) return p;                     // tiny channel depths stay on the VALU kernel
+    if (sh->W < 4 || p.KK > 64) return p;
+    if (sh->IC <= 4 && sh->KH <= 8 && sh->KW <= 8 && !(getenv("QE_F32_STEM") && atoi(getenv("QE_F32_STEM")) == 0)) {
+        // the stem: K = kh x [kw][ic]; tile = whole output rows, as many as 448 / 224 pixel slots and 64 KB of LDS hold
+        if ((int64_t)sh->IC * sh->H * sh->W >= (1ll << 29) || (int64_t)sh->OC * p.OH * p.OW >= (1ll << 29)) return p;
+        p.stem = true;
+        p.cfg = sh->OC > 64 ? 0 : 1;
+        p.MT = p.cfg == 0 ? 128 : 64;
+        p.OCP = (sh->OC + p.MT - 1) / p.MT * p.MT;
+        p.NG = 1;
+        const int max_tiles = p.cfg == 0 ? 7 : 14;
+        if (p.OW > 32 * max_tiles) { p.stem = false; return p; }
+        for (int TH = std::min(p.OH, 32 * max_tiles / p.OW); TH >= 1; --TH) {
+            const int IHT = (TH - 1) * sh->stride + sh->KH, IWP = (p.OW - 1) * sh->stride + 8;
+            const size_t gsz = (size_t)IHT * IWP;
+            const size_t lds = (3 * gsz + F32_TRASH) * 8 + gsz * 4;
+            if (lds <= (size_t)F32_MAX_LDS) { p.TH = TH; p.IHT = IHT; p.IWP = IWP; p.lds = lds; break; }
+        }
+        if (p.TH == 0) { p.stem = false; return p; }
+        const int ni = (p.TH * p.OW + 31) / 32;
+        p.niw = p.cfg == 0 ? 7 : (ni <= 8 ? 4 : 7);          // 2 x 2 waves: 8 or 14 column slots
+        p.wt_bytes = (size_t)sh->KH * 2 * p.OCP * 16 * sizeof(uint16_t);
+        p.ep_off = f32_align(p.wt_bytes, 256);
+        p.total = f32_align(p.ep_off + (size_t)3 * p.OCP * sizeof(float), 256);
+        p.ok = true;
+        return p;
+    }
+    if (sh->IC < 8) return p;                                               // 5..7 channels stay on the VALU kernel
     if ((int64_t)sh->IC * sh->H * sh->W * 8 >= (1ll << 31)) return p;       // 32-bit element offsets inside a tile's (<= 8) images
     if ((int64_t)sh->OC * p.OH * p.OW >= (1ll << 29)) return p;
     p.cfg = sh->OC > 64 ? 0 : 1;
@@ -459,7 +714,8 @@ int launch_conv_f32(const float *x, const qe_qparam *w, const float *bias, const
         pa.OC = sh->OC; pa.IC = sh->IC; pa.KK = p.KK; pa.OCP = p.OCP; pa.NG = p.NG;
         pa.wt = reinterpret_cast<uint16_t *>(wsp);
         pa.ep = reinterpret_cast<float *>(wsp + p.ep_off);
-        hipLaunchKernelGGL(conv_f32_prep_kernel, dim3(p.OCP), dim3(256), 0, s, pa);
+        if (p.stem) hipLaunchKernelGGL(conv_f32_prep_stem_kernel, dim3(p.OCP), dim3(64), 0, s, pa, (int)sh->KH, (int)sh->KW);
+        else hipLaunchKernelGGL(conv_f32_prep_kernel, dim3(p.OCP), dim3(256), 0, s, pa);
         QE_LAUNCH_CHECK();
         if (mode == 1) return QE_OK;
     }
@@ -476,6 +732,13 @@ int launch_conv_f32(const float *x, const qe_qparam *w, const float *bias, const
     const int64_t runs = ((int64_t)a.n_pix_tiles + a.chunk - 1) / a.chunk;
     const int64_t blocks = (runs + 7) / 8 * a.chunk * 8 * a.n_oc_tiles;
     if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
+    if (p.stem) {
+        if (p.cfg == 0) hipLaunchKernelGGL((conv_f32_stem_kernel<4, 1, 7>), dim3((unsigned)blocks), dim3(F32_THREADS), p.lds, s, a);
+        else if (p.niw == 4) hipLaunchKernelGGL((conv_f32_stem_kernel<2, 2, 4>), dim3((unsigned)blocks), dim3(F32_THREADS), p.lds, s, a);
+        else hipLaunchKernelGGL((conv_f32_stem_kernel<2, 2, 7>), dim3((unsigned)blocks), dim3(F32_THREADS), p.lds, s, a);
+        QE_LAUNCH_CHECK();
+        return QE_OK;
+    }
     const int ni = (p.GI * p.TH * p.OW + 31) / 32;           // column tiles the tile really has
 #define QE_F32_LAUNCH(WM, WN, NIW)                                                                                              \
     do {                                                                                                                        \

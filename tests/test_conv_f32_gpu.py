@@ -28,7 +28,14 @@ SHAPES = [
     (2, 40, 17, 19, 24, 5, 1, 2),       # 5x5, odd plane, quads crossing the row end
     (1, 16, 9, 9, 8, 3, 1, 0),          # no padding
     (9, 512, 7, 7, 128, 1, 1, 0),
-    (2, 8, 12, 12, 16, 3, 1, 1),        # the smallest eligible channel depth
+    (2, 8, 12, 12, 16, 3, 1, 1),        # the smallest channel depth of the 16-channel k-step kernel
+    # IC <= 4: the stem kernel (K = kh x [kw][ic])
+    (2, 3, 64, 64, 64, 7, 2, 3),        # ResNet stem at 64x64: 64-channel workgroups, 14 column slots
+    (2, 3, 33, 37, 24, 7, 2, 3),        # odd plane, partial oc tile, quads crossing the row end
+    (2, 4, 20, 24, 48, 5, 1, 2),        # 4 input channels, 5x5, stride 1 (odd fragment columns)
+    (2, 3, 32, 32, 130, 3, 1, 1),       # CIFAR stem: 3x3 / 1, 128-channel workgroups with a ragged second tile
+    (3, 1, 28, 28, 16, 5, 1, 2),        # one input channel
+    (1, 3, 224, 224, 64, 7, 2, 3),      # the ResNet-50 stem at its real size
 ]
 
 
@@ -42,17 +49,17 @@ def test_float_input_mfma_vs_oracle(engine):
                 y, o32, o64 = _run_case(engine, case, via_capi=via_capi)
                 n_mfma += int(case["path"] == 2)
                 _assert_conv_close(y, o64, o32, "f32 %s w%d sgn%d zeros=%s capi=%s" % (shp, wb, wsgn, zeros, via_capi), case["fma"])
-    assert n_mfma >= 80
+    assert n_mfma == len(SHAPES) * 8
 
 
 def test_resnet50_shapes_1e5():
-    """All 22 non-stem ResNet-50 conv shapes (the stem's 3 input channels stay on the VALU kernel), N = 1, headline
-    weight scales, fp32 activations ~ N(0, 0.25): plain 1e-5 absolute against the float64-exact value."""
+    """All 23 ResNet-50 conv shapes (the stem on its own K = kh x [kw][ic] kernel), N = 1, headline weight scales, fp32
+    activations ~ N(0, 0.25): plain 1e-5 absolute against the float64-exact value."""
     rng = np.random.RandomState(8)
     seen = set()
     for layer in resnet50.conv_layers():
         sig = tuple(layer[1:])
-        if sig in seen or layer.IC < 8:
+        if sig in seen:
             continue
         seen.add(sig)
         qw = rng.randint(-128, 128, size=(layer.OC, layer.IC, layer.K, layer.K))
@@ -67,7 +74,7 @@ def test_resnet50_shapes_1e5():
         y = capi.quantconv2d_float_input(_t(xf), wq, _t(bias), sh).cpu().numpy()
         _, o64 = oracle.quantconv2d_float_input(xf, wp, wd, sw, zw, bias, layer.stride, layer.pad, mode="f64", return_f64=True)
         assert np.abs(y.astype(np.float64) - o64).max() <= 1e-5, layer.name
-    assert len(seen) == 22
+    assert len(seen) == 23
 
 
 def test_prepared_and_valu_forms():
