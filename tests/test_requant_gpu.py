@@ -138,3 +138,26 @@ def test_requant_division_free_quotient_is_exact(engine):
             torch.cuda.synchronize()
             assert int(status.item()) == int(st2.item()) == 0
             assert torch.equal(got, ref), "scale %r zero %r: %d codes differ" % (sc, float(z), int((got != ref).sum()))
+
+
+def test_requant_on_the_sweep_shapes(engine):
+    """Every odd shape of the conv sweep (tiny planes, 1x1 pixels, 5x5 / 7x7 taps, ragged everything), 8- and 4-bit
+    activations: fused or two-pass, the codes equal quantize_pack of the fp32 result."""
+    from test_conv_gpu import SWEEP_SHAPES
+    rng = np.random.RandomState(314)
+    n_fused = 0
+    for shp in SWEEP_SHAPES:
+        for ab in (8, 4):
+            case = _random_case(rng, *shp, 8, 1, ab, 0, w_pc=True, a_pc=False, zeros=True, bias=True)
+            sh, xq, wq, bias = _case_tensors(case)
+            prepared = capi.conv_prepare(wq, bias, sh, ab)
+            y = capi.quantconv2d_prepared(xq, wq, bias, sh, prepared)
+            s = (y.abs().max() / 90.0).reshape(1).clamp(min=1e-6)
+            z = torch.tensor([-3.5], device="cuda")
+            rq = capi.requant(s, z, 0.0, 255.0, 8, False)
+            n_fused += capi.requant_path(sh, xq, wq, rq)
+            got, status = capi.quantconv2d_requant_prepared(xq, wq, bias, sh, prepared, rq)
+            ref, _ = capi.quantize_pack(y, s, z, 0.0, 255.0, 8, False)
+            torch.cuda.synchronize()
+            assert int(status.item()) == 0 and torch.equal(got, ref), (shp, ab, int((got != ref).sum()))
+    assert n_fused >= 30
