@@ -37,7 +37,10 @@ struct GenericConvArgs {
     int PT;           // pixels per tile: 64 or 256
     int CI;           // input channels per LDS chunk
     int IHT_max;      // rows of the LDS input band
-    int IWT;          // W + 2*padding
+    int IWT;          // columns of the LDS input band: W + 2*padding, or (PT-1)*stride + KW in row mode
+    int row_mode;     // 1: a tile is PT consecutive pixels of ONE output row and stages only the columns it reads (bands of
+                      //    whole padded rows that would not fit the LDS: very wide images)
+    int tiles_w;      // row mode: tiles per output row
     int tiles_per_image;
     int oc_blocks;
 };
@@ -78,10 +81,21 @@ __global__ __launch_bounds__(GC_THREADS) void conv_generic_kernel(const GenericC
     const int n = bid / a.tiles_per_image;
 
     const int OHW = a.OH * a.OW;
-    const int p0 = tile * a.PT;
-    const int p_last = min(p0 + a.PT, OHW) - 1;
-    const int oh_first = p0 / a.OW;
-    const int oh_last = p_last / a.OW;
+    int p0, p_end, oh_first, oh_last, iw_base;               // pixels [p0, p_end) of the image, first staged input column
+    if (a.row_mode) {
+        oh_first = oh_last = tile / a.tiles_w;
+        const int seg = tile - oh_first * a.tiles_w;
+        p0 = oh_first * a.OW + seg * a.PT;
+        p_end = oh_first * a.OW + min(a.OW, (seg + 1) * a.PT);
+        iw_base = seg * a.PT * a.stride - a.padding;
+    } else {
+        p0 = tile * a.PT;
+        p_end = min(p0 + a.PT, OHW);
+        oh_first = p0 / a.OW;
+        oh_last = (p_end - 1) / a.OW;
+        iw_base = -a.padding;
+    }
+    const int ow_base = a.row_mode ? p0 - oh_first * a.OW : 0;   // first output column the LDS band is aligned to
     const int ih0 = oh_first * a.stride - a.padding;
     const int IHT = (oh_last - oh_first) * a.stride + a.KH;  // <= IHT_max
 
@@ -92,11 +106,11 @@ __global__ __launch_bounds__(GC_THREADS) void conv_generic_kernel(const GenericC
 #pragma unroll
     for (int j = 0; j < GC_PXT; ++j) {
         const int p = p0 + GC_PXT * pxt + j;
-        pv[j] = p < OHW;
+        pv[j] = p < p_end;
         const int oh = pv[j] ? p / a.OW : oh_first;
-        const int ow = pv[j] ? p % a.OW : 0;
+        const int ow = pv[j] ? p % a.OW : ow_base;
         pj[j] = p;
-        xoff[j] = ((oh - oh_first) * a.stride) * a.IWT + ow * a.stride;   // + kh * IWT + kw (LDS column = iw + padding)
+        xoff[j] = ((oh - oh_first) * a.stride) * a.IWT + (ow - ow_base) * a.stride;   // + kh * IWT + kw (LDS column = iw - iw_base)
     }
     const int oc0 = ocb * OCB + ocg * GC_OCT;
 
@@ -120,7 +134,7 @@ __global__ __launch_bounds__(GC_THREADS) void conv_generic_kernel(const GenericC
             const int rem = idx - ci * band;
             const int ihl = rem / a.IWT;
             const int iwl = rem - ihl * a.IWT;
-            const int ih = ih0 + ihl, iw = iwl - a.padding;
+            const int ih = ih0 + ihl, iw = iwl + iw_base;
             float v = 0.0f;
             if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {  // quantconv2d.cu:101
                 const int ic = c0 + ci;
@@ -224,16 +238,27 @@ int launch_conv_generic(bool packed_in, const void *x, const qe_qparam *xq, cons
     const int KK = a.KH * a.KW;
     const size_t per_ic = ((size_t)a.IHT_max * a.IWT + (size_t)KK * OCB) * sizeof(float);
     const size_t budget = 60 * 1024;
-    int ci = (int)(budget / per_ic);
-    if (ci < 1) return QE_ERR_UNSUPPORTED;  // one input channel's band does not fit LDS
+    size_t per = per_ic;
+    a.row_mode = 0; a.tiles_w = 1;
+    if (budget / per < 1) {
+        // one input channel's band of whole padded rows does not fit the LDS (a 7x7 conv on ~1500-pixel-wide images):
+        // tiles of PT pixels inside ONE output row, staging only the (PT-1)*stride + KW columns they read
+        a.row_mode = 1;
+        a.tiles_w = (a.OW + a.PT - 1) / a.PT;
+        a.IWT = (a.PT - 1) * a.stride + a.KW;
+        a.IHT_max = a.KH;
+        per = ((size_t)a.IHT_max * a.IWT + (size_t)KK * OCB) * sizeof(float);
+        if (budget / per < 1) return QE_ERR_UNSUPPORTED;   // (kernels of hundreds of taps: weights of one channel alone exceed the LDS)
+    }
+    int ci = (int)(budget / per);
     if (ci > a.IC) ci = a.IC;
     if (ci > 64) ci = 64;
     a.CI = ci;
-    a.tiles_per_image = (OHW + a.PT - 1) / a.PT;
+    a.tiles_per_image = a.row_mode ? a.OH * a.tiles_w : (OHW + a.PT - 1) / a.PT;
     a.oc_blocks = (a.OC + OCB - 1) / OCB;
     const int64_t blocks = (int64_t)a.N * a.tiles_per_image * a.oc_blocks;
     if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
-    const size_t shmem = (size_t)a.CI * per_ic + 16;
+    const size_t shmem = (size_t)a.CI * per + 16;
     if (packed_in)
         hipLaunchKernelGGL(conv_generic_kernel<true>, dim3((unsigned)blocks), dim3(GC_THREADS), shmem, s, a);
     else

@@ -424,3 +424,15 @@ def test_scale_arrays_must_match_channels_and_deep_reductions_leave_mfma(engine)
     xq, wq = capi.qparam(xp, 8, True, one, one), capi.qparam(wp, 8, True, one, one)
     assert capi.conv_path(capi.conv_shape(1, 2048, 8, 8, 8, 7, 7, 1, 3), xq, wq) == 1      # 100352 terms
     assert capi.conv_path(capi.conv_shape(1, 4096, 8, 8, 8, 7, 7, 1, 3), xq, wq) == 0      # 200704 terms >= 2^17
+
+
+def test_generic_kernel_on_very_wide_images(engine):
+    """A band of whole padded rows of one channel no longer fits the LDS (7x7 on 1400..1600-pixel-wide images): the
+    order-preserving kernel tiles inside one output row instead of refusing -- still bit-identical to the fmaf chain."""
+    rng = np.random.RandomState(23)
+    case = _random_case(rng, 1, 3, 20, 1600, 8, 7, 2, 3, 8, 1, 0, 0, w_pc=True, a_pc=False, zeros=True, bias=True)
+    y, o32, o64 = _run_case(engine, case, via_capi=True)
+    assert case["path"] == 0 and np.array_equal(y, case["fma"])
+    case = _random_case(rng, 1, 4, 12, 1400, 6, 7, 1, 3, 8, 1, 8, 1, w_pc=True, a_pc=True, zeros=True, bias=True)
+    y, o32, o64 = _run_case(engine, case, via_capi=True)
+    assert case["path"] == 0 and np.array_equal(y, case["fma"])
