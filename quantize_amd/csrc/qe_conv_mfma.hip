@@ -607,7 +607,7 @@ bool mfma_conv_requant_fused(const qe_conv_shape *sh, const qe_qparam *x, const 
 {
     if (x->n_param != 1 || rq_bits != 8 || rq_n_param != 1) return false;
     const MfmaPlan p = make_plan(sh, x->n_bits, w->n_bits);
-    if (!p.ok) return false;
+    if (!p.ok || p.sm2d) return false;
     if (p.flat || p.flatg) {
         const qe_conv_shape ds = p.sub ? dense_shape(sh) : *sh;
         const size_t patch = p.flatg ? (size_t)p.GI * p.MT * ds.H * ds.W : (size_t)p.MT * 32 * p.ni;
@@ -823,6 +823,7 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
         return QE_OK;
     }
     if (p.sm2d) {
+        if (rq != nullptr) return QE_ERR_UNSUPPORTED;     // the opt-in LDS-DMA 3x3 kernel has no re-quantising instances
         launch_mfma_sm2d(a, p.niw, p.sm2d, (unsigned)blocks, p.lds, s);
         QE_LAUNCH_CHECK();
         return QE_OK;

@@ -3,12 +3,13 @@
 
 namespace qe {
 
+#define QE_WS_K(NIW, SPLIT, NOPAD, RQ) \
+    hipLaunchKernelGGL((conv_mfma_ws_kernel<NIW, 9, SPLIT, NOPAD, RQ>), dim3(blocks), dim3(2 * MF_THREADS), lds, s, a)
 #define QE_WS(NIW, SPLIT)                                                                                        \
     do {                                                                                                          \
-        if (a.PADW == 0 && a.pad > 0)                                                                             \
-            hipLaunchKernelGGL((conv_mfma_ws_kernel<NIW, 9, SPLIT, true>), dim3(blocks), dim3(2 * MF_THREADS), lds, s, a);  \
-        else                                                                                                      \
-            hipLaunchKernelGGL((conv_mfma_ws_kernel<NIW, 9, SPLIT, false>), dim3(blocks), dim3(2 * MF_THREADS), lds, s, a); \
+        const bool nopad = a.PADW == 0 && a.pad > 0;                                                              \
+        if (a.rq_out != nullptr) { if (nopad) QE_WS_K(NIW, SPLIT, true, true); else QE_WS_K(NIW, SPLIT, false, true); }    \
+        else { if (nopad) QE_WS_K(NIW, SPLIT, true, false); else QE_WS_K(NIW, SPLIT, false, false); }                       \
     } while (0)
 #define QE_WS_SPLIT(NIW) \
     do { if (split == 4) QE_WS(NIW, 4); else if (split == 2) QE_WS(NIW, 2); else QE_WS(NIW, 1); } while (0)

@@ -241,9 +241,10 @@ __device__ __forceinline__ void mfma_epilogue_impl(const MfmaArgs &a, v16i (&acc
         voff[t] = valid[t] ? (uint32_t)(gi * a.OC + 4 * h) * (uint32_t)OHW + (uint32_t)rq : 0u;
     }
 
-    // store of element (register r -> row dr, column slot t): fp32, or its 8-bit code (byte stores: lanes 0-31 = 32 consecutive
-    // bytes of row dr, lanes 32-63 of row dr + 4.  A per-wave LDS patch turned into 16-byte stores was tried: hipcc spilled
-    // 600-900 bytes per lane in EVERY kernel sharing this epilogue, the fp32 instances included; removed.)
+    // store of element (register r -> row dr, column slot t): fp32, or (RQ) its 8-bit code as a byte store (lanes 0-31 = 32
+    // consecutive bytes of row dr, lanes 32-63 of row dr + 4).  Two wider forms were built and measured slower: a per-wave
+    // LDS patch read back as 16-byte pieces (hipcc spilled 600-900 B per lane) and a 4 x 4 byte transpose across lane quads
+    // by DPP + v_perm with dword stores (4.63 against 4.41 ms for the fused stack; 264 B of scratch in the 7-slot kernels).
     auto emit = [&](int r, int dr, int t, float val) __attribute__((always_inline)) {
         if constexpr (RQ) (out_q + (int64_t)dr * OHW)[voff[t]] = (uint8_t)(unsigned)rq_value(rqc, val, bad);
         else (out_w + (int64_t)dr * OHW)[voff[t]] = val;
@@ -365,15 +366,17 @@ __device__ __forceinline__ void mfma_epilogue_impl(const MfmaArgs &a, v16i (&acc
     if constexpr (RQ) rq_report(a, bad);
 }
 
-template <int WM, int WN, int NIW>
+// RQ is a template parameter of the KERNELS that share this epilogue (own instantiations for the fused re-quantisation:
+// as a run-time branch inside one kernel its extra live state pushed the 7-column-tile kernels past 256 VGPRs -- scratch in
+// kernels the fp32 path launches).
+template <int WM, int WN, int NIW, bool RQ = false>
 __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW], const int (&sxs)[NIW],
                                               const bool need_sx, const TileGeom g, const int ot,
                                               const int wm, const int wn, const int col, const int h, const int KK,
                                               const int *ptab = nullptr,   // LDS copy of this tile's rows of a.ws, or null
                                               const float *ctab = nullptr) // LDS [border class][MT] correction table, or null
 {
-    if (a.rq_out != nullptr) mfma_epilogue_impl<WM, WN, NIW, true>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab, ctab);
-    else mfma_epilogue_impl<WM, WN, NIW, false>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab, ctab);
+    mfma_epilogue_impl<WM, WN, NIW, RQ>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab, ctab);
 }
 
 // Asymmetric activations (zx' != 0): the border-aware S_w lookups of the epilogue go to an LDS copy of this tile's MT
@@ -457,7 +460,7 @@ __device__ __forceinline__ bool decode_tile(const MfmaArgs &a, int &pt, int &ot,
 // activations; NS = 32-channel chunks per stage: the 256 threads split into NS groups that each
 // fetch one chunk of the stage, so one HBM round trip feeds NS*KK MFMA steps per column tile.
 // ---------------------------------------------------------------------------------------------
-template <int WM, int WN, int NIW, int KKT, bool X8, int NS>
+template <int WM, int WN, int NIW, int KKT, bool X8, int NS, bool RQ = false>
 __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -698,7 +701,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs
     {
         const float *ctab = stage_ctab<32 * WM>(a, smem, ot, tid, MF_THREADS);
         const int *ptab = ctab ? nullptr : stage_ptab<32 * WM>(a, smem, ot, tid, MF_THREADS);
-        mfma_epilogue<WM, WN, NIW>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab, ctab);
+        mfma_epilogue<WM, WN, NIW, RQ>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab, ctab);
     }
 #ifdef QE_STAMP
     QE_ST(7);       // epilogue stores issued
@@ -729,7 +732,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs
 // it made hipcc spill 700-900 VGPRs (two live copies of the accumulators).
 // Tile geometry, LDS halo image, staging threads and epilogue are the halo kernel's.
 // ---------------------------------------------------------------------------------------------
-template <int WMS, int KKT, int SPLIT>
+template <int WMS, int KKT, int SPLIT, bool RQ = false>
 __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_sm2_kernel(const MfmaArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -972,8 +975,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_sm2_kernel(const Mfma
     QE_ST(6);
     const float *ctab = stage_ctab<MT>(a, smem, ot, tid, MF_THREADS);
     const int *ptab = ctab ? nullptr : stage_ptab<MT>(a, smem, ot, tid, MF_THREADS);
-    mfma_epilogue<2 * WMS, WN, NTC>(a, acc0, sxs, need_sx, g, ot, 2 * wms, wn, col, h, KK, ptab, ctab);
-    mfma_epilogue<2 * WMS, WN, NTC>(a, acc1, sxs, need_sx, g, ot, 2 * wms + 1, wn, col, h, KK, ptab, ctab);
+    mfma_epilogue<2 * WMS, WN, NTC, RQ>(a, acc0, sxs, need_sx, g, ot, 2 * wms, wn, col, h, KK, ptab, ctab);
+    mfma_epilogue<2 * WMS, WN, NTC, RQ>(a, acc1, sxs, need_sx, g, ot, 2 * wms + 1, wn, col, h, KK, ptab, ctab);
 #ifdef QE_STAMP
     QE_ST(7);
     if (a.dbg != nullptr && lane == 0) {
@@ -1001,7 +1004,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_sm2_kernel(const Mfma
 // independent accumulators can keep the matrix pipe issuing back to back).
 // Tile, LDS image layout, operand roles and epilogue are the halo kernel's (4x1 consumer waves).
 // ---------------------------------------------------------------------------------------------
-template <int NIW, int KKT, int SPLIT, bool NOPAD>
+template <int NIW, int KKT, int SPLIT, bool NOPAD, bool RQ = false>
 __global__ __launch_bounds__(2 * MF_THREADS, 2) void conv_mfma_ws_kernel(const MfmaArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1279,7 +1282,7 @@ __global__ __launch_bounds__(2 * MF_THREADS, 2) void conv_mfma_ws_kernel(const M
                 if ((km[t] >> (tap % KW_T)) & 1u) sxs[t] += sxp[pbase + (tap / KW_T) * a.IWP + (tap % KW_T)];
         }
     }
-    mfma_epilogue<WM, WN, NIW>(a, acc, sxs, need_sx, g, ot, cw, 0, col, h, KKT, nullptr, ctab);
+    mfma_epilogue<WM, WN, NIW, RQ>(a, acc, sxs, need_sx, g, ot, cw, 0, col, h, KKT, nullptr, ctab);
 #ifdef QE_STAMP
     QE_ST(7);
     if (a.dbg != nullptr && lane == 0) {
@@ -1299,7 +1302,7 @@ __global__ __launch_bounds__(2 * MF_THREADS, 2) void conv_mfma_ws_kernel(const M
 // 4 consecutive pixels starting at column ow*stride + 4h of row oh*stride + kh.
 //   Wt layout here: [KH][2][OCP][16], byte (kw - 4h)*4 + ic.
 // ---------------------------------------------------------------------------------------------
-template <int WM, int WN, int NIW>
+template <int WM, int WN, int NIW, bool RQ = false>
 __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_smallic_kernel(const MfmaArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1434,7 +1437,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_smallic_kernel(const 
     {
         const float *ctab = stage_ctab<32 * WM>(a, reinterpret_cast<uint8_t *>(smem), ot, tid, MF_THREADS);
         const int *ptab = ctab ? nullptr : stage_ptab<32 * WM>(a, reinterpret_cast<uint8_t *>(smem), ot, tid, MF_THREADS);
-        mfma_epilogue<WM, WN, NIW>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab, ctab);
+        mfma_epilogue<WM, WN, NIW, RQ>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab, ctab);
     }
 }
 
@@ -2088,8 +2091,13 @@ void launch_mfma_flatg(const MfmaArgs &a, int ns, bool wraw, unsigned blocks, si
 void launch_mfma_flat(const MfmaArgs &a, int cfg, int niw, int ns, bool wraw, bool s2, unsigned blocks, size_t lds, hipStream_t s);
 void launch_mfma_flat_x4(const MfmaArgs &a, int niw, int ns, unsigned blocks, size_t lds, hipStream_t s);
 
-#define QE_MFMA_K(WM, WN, NIW, KKT, X8, NS) \
-    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, NIW, KKT, X8, NS>), dim3(blocks), dim3(MF_THREADS), lds, s, a)
+#define QE_MFMA_K(WM, WN, NIW, KKT, X8, NS)                                                                                     \
+    do {                                                                                                                        \
+        if (a.rq_out != nullptr)                                                                                                \
+            hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, NIW, KKT, X8, NS, true>), dim3(blocks), dim3(MF_THREADS), lds, s, a);  \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, NIW, KKT, X8, NS, false>), dim3(blocks), dim3(MF_THREADS), lds, s, a); \
+    } while (0)
 
 // 1x1 convolutions get the multi-chunk stages (ns = 1, 2, 4); sub-8-bit activations only ns = 1
 #define QE_MFMA_LAUNCH(WM, WN, NIW)                                                   \
