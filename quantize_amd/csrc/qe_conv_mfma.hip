@@ -461,6 +461,33 @@ static qe_conv_shape dense_shape(const qe_conv_shape *sh)
     return d;
 }
 
+// 4-bit activations of a stride-2 1x1 layer: out[r][ow] = 8-bit stored code (q + 128) of in[r_in][2 ow], r = (plane, oh),
+// r_in = plane H + 2 oh.  One thread per 8 output bytes = 8 input bytes (16 elements, the even ones are the low nibbles):
+// one byte-aligned 8-byte load, a mask and an add, one 8-byte store; the last unit of a row goes byte by byte.
+// Replaces expand_codes_s8 over the WHOLE tensor followed by subsample_kernel / the in-kernel stride-2 staging.
+__global__ __launch_bounds__(256) void subsample_x4_kernel(const uint8_t *__restrict__ x, uint8_t *__restrict__ y, int64_t n_rows,
+                                                           int H, int W, int OH, int OW, int sign)
+{
+    const int nq = (OW + 7) >> 3;
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= n_rows * nq) return;
+    const int64_t r = u / nq;
+    const int q = (int)(u - r * nq);
+    const int64_t plane = r / OH;
+    const int oh = (int)(r - plane * OH);
+    const uint8_t *src = x + ((plane * H + 2 * oh) * (int64_t)W >> 1) + 8 * q;      // 2 elements per byte: input column 16 q
+    uint8_t *dst = y + r * OW + 8 * q;
+    const uint64_t add = sign ? 0x7878787878787878ull : 0x8080808080808080ull;     // q + 128 = nibble - 8 + 128 | nibble + 128
+    if (8 * q + 8 <= OW) {
+        uint64_t v;
+        __builtin_memcpy(&v, src, 8);
+        v = (v & 0x0f0f0f0f0f0f0f0full) + add;
+        __builtin_memcpy(dst, &v, 8);
+    } else {
+        for (int j = 0; 8 * q + j < OW; ++j) dst[j] = (uint8_t)((src[j] & 0x0f) + (uint8_t)add);
+    }
+}
+
 static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits, int w_bits)
 {
     const bool expand = x_bits < 8 && !(getenv("QE_EXPAND") && atoi(getenv("QE_EXPAND")) == 0);
@@ -473,8 +500,12 @@ static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits, int w_bits)
     // kernel's in-kernel stride-2 staging.  QE_SUBSAMPLE=1 forces the gather, =0 disables it.
     const int sub_env = getenv("QE_SUBSAMPLE") ? atoi(getenv("QE_SUBSAMPLE")) : -1;
     const int p_out = ((sh->H - 1) / std::max(1, (int)sh->stride) + 1) * ((sh->W - 1) / std::max(1, (int)sh->stride) + 1);
+    // 4-bit activations, stride 2: ONE pass reads the even nibbles of the even rows and writes dense 8-bit codes
+    // (subsample_x4_kernel) instead of expanding the whole tensor first -- there the gather pays on every plane size
+    const bool sub_x4 = x_bits == 4 && expand && sh->stride == 2 && (sh->W % 2) == 0 && ((int64_t)sh->H * sh->W % 2) == 0 &&
+                        !(getenv("QE_SUB_X4") && atoi(getenv("QE_SUB_X4")) == 0);
     const bool sub = sh->KH == 1 && sh->KW == 1 && sh->stride > 1 && sh->padding == 0 && xb == 8 && sub_env != 0 &&
-                     (sub_env > 0 || p_out <= 256);
+                     (sub_env > 0 || p_out <= 256 || sub_x4);
     const qe_conv_shape ds = dense_shape(sh);
     // 4-bit activations on a stride-1 1x1 layer with 128-channel workgroups: the flat kernel unpacks the nibbles in its
     // staging registers (QE_X4=0: expansion pass + 8-bit kernel as for every other sub-8-bit case)
@@ -653,7 +684,27 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
         }
     }
     qe_qparam xe;
-    if (p.expand && mode != 1) {
+    qe_qparam xs;
+    qe_conv_shape shd;
+    bool sub_done = false;
+    if (p.sub && p.expand && mode != 1 && x->n_bits == 4 && sh->stride == 2) {
+        shd = dense_shape(sh);
+        const int64_t n_rows = (int64_t)sh->N * sh->IC * shd.H;
+        const int64_t units = n_rows * ((shd.W + 7) / 8);
+        const int64_t blocks = (units + 255) / 256;
+        if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(subsample_x4_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint8_t *>(x->data),
+                           wsp + p.sub_off, n_rows, (int)sh->H, (int)sh->W, (int)shd.H, (int)shd.W, (int)x->sign);
+        QE_LAUNCH_CHECK();
+        xs = *x;
+        xs.data = wsp + p.sub_off;
+        xs.n_bits = 8;
+        xs.sign = 1;
+        x = &xs;
+        sh = &shd;
+        sub_done = true;
+    }
+    if (p.expand && mode != 1 && !sub_done) {
         const int64_t n = (int64_t)sh->N * sh->IC * sh->H * sh->W;
         const int rc = expand_codes_s8(static_cast<const uint8_t *>(x->data), n, x->n_bits, x->sign, wsp + p.xe_off, s);
         if (rc != QE_OK) return rc;
@@ -663,9 +714,8 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
         xe.sign = 1;
         x = &xe;
     }
-    qe_qparam xs;
-    qe_conv_shape shd;
-    if (p.sub && mode == 1) {
+    if (sub_done) {
+    } else if (p.sub && mode == 1) {
         shd = dense_shape(sh);
         sh = &shd;
     } else if (p.sub) {

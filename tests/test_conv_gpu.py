@@ -436,3 +436,28 @@ def test_generic_kernel_on_very_wide_images(engine):
     case = _random_case(rng, 1, 4, 12, 1400, 6, 7, 1, 3, 8, 1, 8, 1, w_pc=True, a_pc=True, zeros=True, bias=True)
     y, o32, o64 = _run_case(engine, case, via_capi=True)
     assert case["path"] == 0 and np.array_equal(y, case["fma"])
+
+
+@pytest.mark.parametrize("sub_x4", ["1", "0"])
+def test_4bit_activations_on_strided_1x1(engine, sub_x4):
+    """4-bit activations of a stride-2 1x1 layer: one pass picks the even nibbles of the even rows and writes dense 8-bit
+    codes (QE_SUB_X4, default on) instead of expanding the whole tensor first; signed and unsigned codes, row lengths that
+    are not a multiple of 8 output pixels, planes from 56x56 down to 14x14, with the pass disabled as well."""
+    import os
+    rng = np.random.RandomState(77)
+    old = os.environ.get("QE_SUB_X4")
+    os.environ["QE_SUB_X4"] = sub_x4
+    try:
+        for shp in [(2, 128, 56, 56, 160, 1, 2, 0), (3, 256, 14, 14, 140, 1, 2, 0), (2, 64, 28, 28, 130, 1, 2, 0),
+                    (2, 64, 30, 26, 40, 1, 2, 0), (3, 96, 12, 6, 72, 1, 2, 0)]:
+            for (wb, wsgn, asgn) in [(8, 1, 1), (4, 1, 0)]:
+                for zeros in (False, True):
+                    case = _random_case(rng, *shp, wb, wsgn, 4, asgn, w_pc=True, a_pc=False, zeros=zeros, bias=True)
+                    y, o32, o64 = _run_case(engine, case, via_capi=True)
+                    assert case["path"] == 1
+                    _assert_conv_close(y, o64, o32, "sub_x4=%s %s %s zeros=%s" % (sub_x4, shp, (wb, wsgn, asgn), zeros), case["fma"])
+    finally:
+        if old is None:
+            os.environ.pop("QE_SUB_X4", None)
+        else:
+            os.environ["QE_SUB_X4"] = old
