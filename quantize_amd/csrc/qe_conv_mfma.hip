@@ -199,6 +199,7 @@ struct MfmaPlan {
     size_t xe_off = 0;
     bool flatg = false;        // flat 1x1 kernel for small planes (several whole images per tile)
     bool sub = false;          // strided 1x1: the sampled pixels are gathered into a dense tensor first
+    bool sub_x4 = false;       // ... straight from the 4-bit stream (subsample_x4_kernel), no expansion pass
     size_t sub_off = 0;
     int PADW = 0;
     size_t lds = 0;
@@ -461,6 +462,50 @@ static qe_conv_shape dense_shape(const qe_conv_shape *sh)
     return d;
 }
 
+// Stride-2 gather without index divisions: a plane's OH x nq units (nq = 16-byte pieces per even input row, a power of two)
+// sit in UP = 2^LOG_UP consecutive threads, thread u -> row u / nq, piece u % nq by shifts; a block takes 256 / UP planes per
+// round and 4 rounds, all 4 loads of a thread issued before its stores.  One unaligned 16-byte load (it may run into the
+// following odd row, never past the tensor: 16 nq <= 2 W, H even), two v_perm keep the even bytes, one 8-byte store (the last
+// piece of a row in 4 / 2 / 1-byte steps).  The round-1 kernel spent ~3 integer divisions per unit and took byte gathers
+// on 14-wide rows: 2.5 TB/s over the two ResNet-50 gathers.
+template <int LOG_UP>
+__global__ __launch_bounds__(256) void subsample2_kernel(const uint8_t *__restrict__ x, uint8_t *__restrict__ y, int64_t n_planes,
+                                                         int H, int W, int OH, int OW, int log_nq)
+{
+    constexpr int UP = 1 << LOG_UP, PPR = 256 / UP, ROUNDS = 4;
+    const int u = threadIdx.x & (UP - 1);
+    const int oh = u >> log_nq, q = u & ((1 << log_nq) - 1);
+    const bool unit_ok = oh < OH && 8 * q < OW;
+    const int64_t plane0 = (int64_t)blockIdx.x * (PPR * ROUNDS) + (threadIdx.x >> LOG_UP);
+    uint4 d[ROUNDS];
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+        const int64_t pl = plane0 + k * PPR;
+        const bool ok = unit_ok && pl < n_planes;
+        const uint8_t *src = x + (ok ? (pl * H + 2 * oh) * (int64_t)W + 16 * q : 0);
+        __builtin_memcpy(&d[k], src, 16);
+    }
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+        const int64_t pl = plane0 + k * PPR;
+        if (!(unit_ok && pl < n_planes)) continue;
+        const uint32_t lo = __builtin_amdgcn_perm(d[k].y, d[k].x, 0x06040200u);   // even bytes of dwords 0, 1
+        const uint32_t hi = __builtin_amdgcn_perm(d[k].w, d[k].z, 0x06040200u);
+        uint8_t *dst = y + (pl * OH + oh) * (int64_t)OW + 8 * q;
+        const int left = OW - 8 * q;
+        if (left >= 8) {
+            const uint2 o = make_uint2(lo, hi);
+            __builtin_memcpy(dst, &o, 8);
+        } else {
+            uint32_t v = lo;
+            int done = 0;
+            if (left >= 4) { __builtin_memcpy(dst, &lo, 4); done = 4; v = hi; }
+            if (left - done >= 2) { const uint16_t h2 = (uint16_t)v; __builtin_memcpy(dst + done, &h2, 2); done += 2; v >>= 16; }
+            if (left - done >= 1) dst[done] = (uint8_t)v;
+        }
+    }
+}
+
 // 4-bit activations of a stride-2 1x1 layer: out[r][ow] = 8-bit stored code (q + 128) of in[r_in][2 ow], r = (plane, oh),
 // r_in = plane H + 2 oh.  One thread per 8 output bytes = 8 input bytes (16 elements, the even ones are the low nibbles):
 // one byte-aligned 8-byte load, a mask and an add, one 8-byte store; the last unit of a row goes byte by byte.
@@ -521,6 +566,7 @@ static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits, int w_bits)
     p.prep_total = p.ok ? p.total : 0;
     if (p.ok && sub) {
         p.sub = true;
+        p.sub_x4 = sub_x4;
         p.sub_off = align_up(p.total, 256);
         p.total = p.sub_off + align_up((size_t)ds.N * ds.IC * ds.H * ds.W, 256);
     } else if (sub) {
@@ -687,7 +733,7 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     qe_qparam xs;
     qe_conv_shape shd;
     bool sub_done = false;
-    if (p.sub && p.expand && mode != 1 && x->n_bits == 4 && sh->stride == 2) {
+    if (p.sub && p.sub_x4 && mode != 1) {
         shd = dense_shape(sh);
         const int64_t n_rows = (int64_t)sh->N * sh->IC * shd.H;
         const int64_t units = n_rows * ((shd.W + 7) / 8);
@@ -721,13 +767,41 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     } else if (p.sub) {
         shd = dense_shape(sh);
         const int64_t n_planes = (int64_t)sh->N * sh->IC;
+        {   // stride 2, even H, a power-of-two number of 16-byte pieces per row that stays inside two input rows: subsample2_kernel
+            const int nq = (shd.W + 7) / 8;
+            int log_nq = 0;
+            while ((1 << log_nq) < nq) ++log_nq;
+            const int units2 = shd.H << log_nq;
+            if (sh->stride == 2 && (sh->H % 2) == 0 && (1 << log_nq) == nq && 16 * nq <= 2 * sh->W && units2 <= 256 &&
+                !(getenv("QE_SUB2") && atoi(getenv("QE_SUB2")) == 0)) {
+                int log_up = 3;
+                while ((1 << log_up) < units2) ++log_up;
+                const int ppb = (256 >> log_up) * 4;
+                const int64_t blocks2 = (n_planes + ppb - 1) / ppb;
+                if (blocks2 > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
+#define QE_SUB2(L) hipLaunchKernelGGL(subsample2_kernel<L>, dim3((unsigned)blocks2), dim3(256), 0, s, static_cast<const uint8_t *>(x->data), \
+                                      wsp + p.sub_off, n_planes, (int)sh->H, (int)sh->W, (int)shd.H, (int)shd.W, log_nq)
+                switch (log_up) {
+                    case 3: QE_SUB2(3); break; case 4: QE_SUB2(4); break; case 5: QE_SUB2(5); break;
+                    case 6: QE_SUB2(6); break; case 7: QE_SUB2(7); break; default: QE_SUB2(8); break;
+                }
+#undef QE_SUB2
+                QE_LAUNCH_CHECK();
+                xs = *x;
+                xs.data = wsp + p.sub_off;
+                x = &xs;
+                sh = &shd;
+                sub_done = true;
+            }
+        }
         const bool wide = sh->stride == 2 && (sh->W % 4) == 0 && sh->W >= 16;
         const int opt = wide ? 8 : 4;
         const int units = shd.H * ((shd.W + opt - 1) / opt);
         const int ppb = units >= 1024 ? 1 : 1024 / units;   // 4 units per thread
         const int64_t blocks = (n_planes + ppb - 1) / ppb;
         if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
-        if (wide)
+        if (sub_done) {
+        } else if (wide)
             hipLaunchKernelGGL(subsample_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint8_t *>(x->data),
                                wsp + p.sub_off, n_planes, (int)sh->H, (int)sh->W, (int)shd.H, (int)shd.W, (int)sh->stride);
         else
