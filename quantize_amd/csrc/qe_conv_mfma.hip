@@ -290,6 +290,11 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits, bool
                 static const int cands[3] = {7, 5, 4};
                 for (int c : cands)
                     if (waste(c) < waste(tiles) - 0.03) tiles = c;
+                // measured exceptions (profiles/r02y_ab_flat_niw.txt, cold per-layer A/B on ResNet-50 at batch 256):
+                //   128 -> 512 @28x28: 128-pixel tiles (a fourth workgroup per CU) beat the better-fitting 160-pixel ones by 5 %;
+                //   512 -> 128 @28x28: 224-pixel tiles beat 160-pixel ones by 4.5 % (1024 workgroups = two full rounds).
+                if (P == 784 && sh->IC <= 128 && sh->OC >= 256) tiles = 4;
+                if (P == 784 && sh->IC >= 512 && sh->OC <= 128) tiles = 7;
             }
         }
         const int ntp = 32 * tiles;
@@ -298,6 +303,8 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits, bool
         p.NS = 1;
         int ns_max = 4;
         if (const char *e = getenv("QE_FLAT_NS")) ns_max = std::max(1, atoi(e));   // tuning knob
+        // 64 -> 256 @56x56 (write-bound, two chunks in all): one chunk per stage is 3 % faster (r02y_ab_flat_ns.txt)
+        if (!getenv("QE_FLAT_NS") && nch == 2 && sh->OC >= 4 * sh->IC && P >= 3136) ns_max = 1;
         for (int cand = 4; cand > 1; cand >>= 1)
             if (cand <= ns_max && cand <= nch && (size_t)(32 * cand) * rstr + (size_t)ntp * 4 <= (size_t)MF_MAX_LDS) { p.NS = cand; break; }
         p.lds = std::max((size_t)(32 * p.NS) * rstr, (size_t)4 * 32 * 36 * 4) + (size_t)ntp * 4;
