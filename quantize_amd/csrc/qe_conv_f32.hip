@@ -337,6 +337,10 @@ __global__ __launch_bounds__(F32_THREADS, 2) void conv_f32_mfma_kernel(const F32
     const int OHW = a.OH * a.OW;
     const bool full_oc = (ot + 1) * MT <= a.OC;
     float *out_w = a.out + ((int64_t)n0 * a.OC + ot * MT + wm * 32) * OHW + (int64_t)oh0 * a.OW;
+    // 16-byte stores need one image per tile, 16-byte aligned rows and the halo image at least as large as the 4 patches
+    const bool use_patch = a.GI == 1 && (OHW & 3) == 0 && ((oh0 * a.OW) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
+                           6 * NS * GSZ * 16 >= 4 * 32 * 36 * 4 && !(need_sx && false);
+    float *patch = reinterpret_cast<float *>(smem) + wave * (32 * 36);
 #pragma unroll
     for (int t = 0; t < NIW; ++t) {
         const int q = (wn + t * WN) * 32 + col;
@@ -346,6 +350,28 @@ __global__ __launch_bounds__(F32_THREADS, 2) void conv_f32_mfma_kernel(const F32
         const uint32_t voff = valid ? (uint32_t)(gi * a.OC + 4 * h) * (uint32_t)OHW + (uint32_t)rq : 0u;
         const int q0 = (wn + t * WN) * 32;
         const bool whole = full_oc && q0 + 32 <= NT;            // wave-uniform: plain stores
+        if (whole && use_patch) {
+            // whole 32 x 32 tile of one image: through the wave's LDS patch (the halo image is dead) and out as 16-byte
+            // pieces, 8 rows x 128 contiguous bytes per store instruction instead of 2 x 128 (the write-bound 1x1 layers
+            // stored at 3.5 TB/s against 5.1 TB/s on the packed path, which has stored this way since round 1)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dr = (r & 3) + 8 * (r >> 2);
+                float v = acc[t][r];
+                if (need_sx) v = fmaf(-zw[r], sxs[t], v);
+                patch[(dr + 4 * h) * 36 + col] = fmaf(sw[r], v, bi[r]);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): same wave wrote and reads
+            float *tile = out_w + q0 + 4 * (lane & 7);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int rt = 8 * k + (lane >> 3);
+                const float4 o4 = *reinterpret_cast<const float4 *>(patch + rt * 36 + 4 * (lane & 7));
+                *reinterpret_cast<float4 *>(tile + (int64_t)rt * OHW) = o4;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // reads done before the next tile overwrites the patch
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int dr = (r & 3) + 8 * (r >> 2);
@@ -567,12 +593,37 @@ __global__ __launch_bounds__(F32_THREADS, 2) void conv_f32_stem_kernel(const F32
     const int OHW = a.OH * a.OW;
     const bool full_oc = (ot + 1) * MT <= a.OC;
     float *out_w = a.out + ((int64_t)n0 * a.OC + ot * MT + wm * 32) * OHW + (int64_t)oh0 * a.OW;
+    // whole tiles go through the wave's LDS patch and out as 16-byte pieces (as in conv_f32_mfma_kernel); the barrier makes
+    // sure every wave has read its last fragments from the halo image the patches overwrite
+    const bool use_patch = (OHW & 3) == 0 && ((oh0 * a.OW) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
+                           3 * GSZ * 8 >= 4 * 32 * 36 * 4;
+    float *patch = reinterpret_cast<float *>(smem) + wave * (32 * 36);
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < NIW; ++t) {
         const int q = (wn + t * WN) * 32 + col;
         const bool valid = q < NT;
         const uint32_t voff = valid ? (uint32_t)(4 * h) * (uint32_t)OHW + (uint32_t)q : 0u;
         const bool whole = full_oc && (wn + t * WN) * 32 + 32 <= NT;            // wave-uniform: plain stores
+        if (whole && use_patch) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dr = (r & 3) + 8 * (r >> 2);
+                float v = acc[t][r];
+                if (need_sx) v = fmaf(-zw[r], sxs[t], v);
+                patch[(dr + 4 * h) * 36 + col] = fmaf(sw[r], v, bi[r]);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): same wave wrote and reads
+            float *tile = out_w + (wn + t * WN) * 32 + 4 * (lane & 7);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int rt = 8 * k + (lane >> 3);
+                const float4 o4 = *reinterpret_cast<const float4 *>(patch + rt * 36 + 4 * (lane & 7));
+                *reinterpret_cast<float4 *>(tile + (int64_t)rt * OHW) = o4;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int dr = (r & 3) + 8 * (r >> 2);
