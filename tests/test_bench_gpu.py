@@ -36,4 +36,5 @@ def test_bench_json_contract():
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
-    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert cb["kind"] == "reference" and cb["cores"] >= 1 and cb["value"] > 0    # the reference's F.conv2d fallback (north_star)
+    assert d["cpu_baseline_port"]["kind"] == "port" and d["cpu_baseline_port"]["value"] > 0

@@ -183,7 +183,8 @@ def test_vit_shapes_and_row_independence(engine):
     o64 = oracle.quantlinear(*[t.cpu().numpy() for t in engine.tpack(qx[r].contiguous(), 8, True)],
                              sx[r].cpu().numpy(), zx[r].cpu().numpy(), wp.cpu().numpy(), wd.cpu().numpy(),
                              sw.cpu().numpy(), zw.cpu().numpy(), bias.cpu().numpy(), mode="f64", return_f64=True)[1]
-    assert np.abs(y[r].cpu().numpy().astype(np.float64) - o64).max() <= 1e-5 * max(1.0, float(np.abs(o64).max()))
+    # north_star's bar is ABSOLUTE: 1e-5 at these operand scales (|out| stays below 1.5 here)
+    assert np.abs(y[r].cpu().numpy().astype(np.float64) - o64).max() <= 1e-5
 
 
 def test_error_messages(engine):
