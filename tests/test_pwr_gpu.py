@@ -26,6 +26,8 @@ SHAPES = [
     (2, 256, 56, 56, 128, 1, 1, 0),     # layer2.0.conv1
     (40, 64, 14, 14, 192, 1, 1, 0),     # more tiles than XCDs
     (1, 128, 28, 16, 128, 1, 1, 0),     # 448-pixel planes: 2 tiles of 224
+    (3, 128, 14, 14, 288, 1, 1, 0),     # persistent form, 9 strips on 8 waves (one wave reloads weights, seven keep theirs)
+    (5, 64, 28, 28, 512, 1, 1, 0),      # persistent form, 20 tiles, two strips per wave
 ]
 
 
@@ -42,9 +44,17 @@ def _with_env(env, fn):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("pwr", ["1", "0"])
+@pytest.mark.parametrize("pwr", ["1", "0", "grid3", "nopersist"])
 def test_pwr_vs_oracle(engine, pwr):
+    """pwr = 1: default routing (persistent double-buffered form for IC <= 128 / OC >= 256, one tile per workgroup otherwise);
+    grid3: the persistent form on THREE workgroups, so each walks many tiles (tile switch, buffer swap, weight reload and
+    the patched tail of the tensor in a late tile); nopersist: every instance of the one-tile form; 0: kernel disabled."""
     rng = np.random.RandomState(4242)
+    env = {"QE_PWR": "0" if pwr == "0" else "1"}
+    if pwr == "grid3":
+        env["QE_PWR_GRID"] = "3"
+    if pwr == "nopersist":
+        env["QE_PWR_PERSIST"] = "0"
 
     def run():
         for shp in SHAPES:
@@ -55,7 +65,7 @@ def test_pwr_vs_oracle(engine, pwr):
                 _assert_conv_close(y, o64, o32, "pwr=%s %s asgn=%d zeros=%s w_pc=%s" % (pwr, shp, asgn, zeros, w_pc), case["fma"])
                 if not zeros:
                     assert np.abs(y.astype(np.float64) - o64).max() <= 1e-5
-    _with_env({"QE_PWR": pwr}, run)
+    _with_env(env, run)
 
 
 @pytest.mark.parametrize("groups", ["2", "4"])
