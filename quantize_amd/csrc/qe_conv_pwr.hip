@@ -42,6 +42,7 @@ struct PwrArgs {
     int tiles_per_image, n_pix_tiles, chunk;
     int n_groups;              // output-channel groups a pixel tile is split over (workgroups per tile)
     int strips_per_group;      // 32-channel strips of one group
+    unsigned long long *dbg;   // diagnostic builds (-DQE_STAMP) only: per-wave phase cycle sums
 };
 
 // NT column tiles of 32 pixel slots (odd), of which the first TW pixels are real: every tile of a launch has the same
@@ -61,6 +62,10 @@ template <int NT, int WAVES, int KS, int TW> struct PwrGeom {
     static constexpr int LDS = XBYTES + TAB + WAVES * PATCH;
 };
 
+// (Tried and removed: every accumulator register straight out as one buffer_store_dword -- two 128-byte row segments per
+// instruction, no LDS round trip, 3 vector instructions per element.  In-kernel stamps: under load the epilogues' issue
+// time went UP, 50-57 k -> 78 k cycles per wave on 256 -> 1024 @14x14: a back-pressured store costs its 500+ cycles per
+// INSTRUCTION whatever its width, so the 1 KiB stores of the patch form are worth their LDS round trip.)
 template <int NT, int WAVES, int KS, int TW>
 __global__ __launch_bounds__(64 * WAVES, 2) void conv_pwr_kernel(const PwrArgs a)
 {
@@ -74,6 +79,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_pwr_kernel(const PwrArgs a
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, h = lane >> 5;
     const int P = a.P;
+#ifdef QE_STAMP
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = qe_stamp();
+    const unsigned long long tstart = tprev;
+#endif
 
     // ---- tile decode: XCD-aware block map (the scheme of block_to_tile; "oc tile" = channel group here) ----------
     int pt, og;
@@ -175,6 +185,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_pwr_kernel(const PwrArgs a
     }
     const bool need_sx = __builtin_amdgcn_ballot_w64(any_zw) != 0ull;
 
+    QE_ST(0);   // prologue: requests issued
     // ---- recode the pieces this lane fetched (u ^ 0x80: signed q, or unsigned q - 128), once for all strips --------
     if (n_my > 0) wait_w(std::integral_constant<int, 0>{}); else __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): tile pieces and first weights landed
 #pragma unroll
@@ -187,7 +198,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_pwr_kernel(const PwrArgs a
             *slot = v;
         }
     }
+    QE_ST(1);   // tile landed + recode pass
     __syncthreads();                                          // the only barrier: the tile is complete
+    QE_ST(2);   // barrier
     if (n_my <= 0) return;
 
     // transposed-read base of this lane: row (16 h + i16 / 2) of a 32-channel step, 16-pixel group (lane >> 4) & 1
@@ -237,8 +250,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_pwr_kernel(const PwrArgs a
         }
     };
 
-    // epilogue of the strip whose sums sit in acc / swacc; (e_sw, e_zw, e_bi) = its lane's channel constants
-    // epilogue of the strip whose sums sit in acc / swacc; (e_sw, e_zw, e_bi) = its lane's channel constants
+    // epilogue of the strip whose sums sit in acc / swacc; (e_sw, e_zw, e_bi) = its lane's channel constants.
+    // next >= 0: the next strip's weights are requested in front of this strip's N_YOUNGER stores (vmcnt is a 6-bit in-order
+    // counter: the wait for the weights names the stores issued behind them).
+    constexpr int N_YOUNGER = 4 * NRB;
+    static_assert(N_YOUNGER <= 63, "vmcnt is a 6-bit counter");
     auto epilogue = [&](int strip, float e_sw, float e_zw, float e_bi) __attribute__((always_inline)) {
         const int oc0 = strip * 32;
         {
@@ -296,14 +312,29 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_pwr_kernel(const PwrArgs a
     // strip s + 1's weights are requested, strip s is stored, strip s + 1 is multiplied.  The wait for the weights leaves
     // the strip's 4 NRB stores in flight (vmcnt(4 NRB)): no store acknowledgement is ever waited for.
     if (need_sx) mma_strip(std::true_type{}); else mma_strip(std::false_type{});
+    QE_ST(3);   // K loops
     for (int s = 0; s + 1 < n_my; ++s) {
         const float e_sw = c_sw, e_zw = c_zw, e_bi = c_bi;
         load_w(strip0 + (s + 1) * WAVES);
         epilogue(strip0 + s * WAVES, e_sw, e_zw, e_bi);
-        wait_w(std::integral_constant<int, 4 * NRB>{});
+        QE_ST(4);   // epilogues: conversions, patch round trips, stores issued
+        wait_w(std::integral_constant<int, N_YOUNGER>{});
+        QE_ST(5);   // wait for the next strip's weights
         mma_strip(std::false_type{});
+        QE_ST(3);
     }
     epilogue(strip0 + (n_my - 1) * WAVES, c_sw, c_zw, c_bi);
+#ifdef QE_STAMP
+    QE_ST(4);
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): stores acknowledged
+    QE_ST(6);   // store drain
+    if (a.dbg != nullptr && lane == 0) {
+        unsigned long long *o = a.dbg + ((size_t)blockIdx.x * WAVES + wave) * 10;
+        for (int i = 0; i < 8; ++i) o[i] = st[i];
+        o[8] = tprev - tstart;
+        o[9] = tstart;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -401,7 +432,9 @@ __global__ __launch_bounds__(512, 2) void conv_pwrp_kernel(const PwrArgs a)
                 const uint32_t dst = __builtin_amdgcn_readfirstlane(smem_lds + (uint32_t)(buf * G::XBYTES + 1024 * (wave + WAVES * i)));
                 unsigned keep;
                 unsigned long long ex;
-                asm volatile("s_mov_b64 %1, exec\n\ts_and_b64 exec, exec, %4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                // `live` is a ballot (a subset of EXEC); s_mov, not s_and: nothing here may write SCC, hipcc keeps a compare
+                // alive across the statement
+                asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
                              "global_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0\n\ts_mov_b64 exec, %1"
                              : "=&s"(keep), "=&s"(ex) : "v"(gsrc), "s"(dst), "s"(live) : "memory");
             }
@@ -571,6 +604,8 @@ __global__ __launch_bounds__(512, 2) void conv_pwrp_kernel(const PwrArgs a)
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+extern unsigned long long *g_mfma_dbg;   // qe_conv_mfma.hip (diagnostic builds)
+
 struct PwrPlan {
     int tw = 0, waves = 0, ks = 0, groups = 1;
     bool persistent = false;
@@ -599,7 +634,7 @@ static bool pwr_plan(const qe_conv_shape *sh, const qe_qparam *x, const qe_qpara
     if (const char *e = getenv("QE_PWR_GROUPS")) { const int v = atoi(e); if (v >= 1 && strips % v == 0) groups = v; }
     pl->tw = tw; pl->waves = waves; pl->ks = ks; pl->groups = groups;
     // IC <= 128 with at least one strip for each of 8 waves: the persistent double-buffered form (QE_PWR_PERSIST=0: off)
-    pl->persistent = ks <= 4 && sh->OC >= 256 && groups == 1 && !(getenv("QE_PWR_PERSIST") && atoi(getenv("QE_PWR_PERSIST")) == 0);
+    pl->persistent = ks <= 4 && sh->OC >= 256 && groups == 1 && (getenv("QE_PWR_PERSIST") && atoi(getenv("QE_PWR_PERSIST")) == 1);   // opt-in: +13-20 % against one tile per workgroup (profiles/r03d_ab_persist.txt)
     return true;
 }
 
@@ -622,6 +657,7 @@ int launch_pwr(const qe_qparam *x, const qe_qparam *w, const float *bias, const 
     a.n_pix_tiles = sh->N * a.tiles_per_image;
     a.n_groups = pl.groups;
     a.strips_per_group = sh->OC / 32 / pl.groups;
+    a.dbg = g_mfma_dbg;
     const int64_t per_xcd = ((int64_t)a.n_pix_tiles + 7) / 8;
     a.chunk = (int)(per_xcd < 1 ? 1 : per_xcd);
     if (const char *ci = getenv("QE_CHUNK_IMAGES")) {

@@ -44,17 +44,18 @@ def _with_env(env, fn):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("pwr", ["1", "0", "grid3", "nopersist"])
+@pytest.mark.parametrize("pwr", ["1", "0", "grid3", "persist"])
 def test_pwr_vs_oracle(engine, pwr):
-    """pwr = 1: default routing (persistent double-buffered form for IC <= 128 / OC >= 256, one tile per workgroup otherwise);
-    grid3: the persistent form on THREE workgroups, so each walks many tiles (tile switch, buffer swap, weight reload and
-    the patched tail of the tensor in a late tile); nopersist: every instance of the one-tile form; 0: kernel disabled."""
+    """pwr = 1: default routing (one tile per workgroup); persist: the opt-in persistent double-buffered form for IC <= 128 / OC >= 256;
+    grid3: that form on THREE workgroups, so each walks many tiles (tile switch, buffer swap, weight reload and the patched
+    tail of the tensor in a late tile); 0: kernel disabled."""
     rng = np.random.RandomState(4242)
     env = {"QE_PWR": "0" if pwr == "0" else "1"}
     if pwr == "grid3":
         env["QE_PWR_GRID"] = "3"
-    if pwr == "nopersist":
-        env["QE_PWR_PERSIST"] = "0"
+        env["QE_PWR_PERSIST"] = "1"
+    if pwr == "persist":
+        env["QE_PWR_PERSIST"] = "1"
 
     def run():
         for shp in SHAPES:
