@@ -936,15 +936,6 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
         a.ctab = (a.ptab_off != 0 && a.n_top + a.n_bot < p.OH && a.n_lft + a.n_rgt < p.OW &&
                   ncls <= (sh->KH + 1) * (sh->KW + 1) && !(getenv("QE_CTAB") && atoi(getenv("QE_CTAB")) == 0)) ? 1 : 0;
     }
-    // lane = pixel epilogues (3x3 kernels, stem): whole 32 x 32 tiles leave through a per-wave LDS patch as 1 KiB stores
-    // (mfma_epilogue_impl).  Needs one image per tile, 16-byte aligned row pieces and room for 4 patches; QE_EPI_PATCH=0: off.
-    a.epi_patch = 0;
-    if (!p.flat && !p.flatg && !p.sm2d && !p.ws && rq == nullptr && p.GI == 1 && (p.OH * p.OW) % 4 == 0 &&
-        (p.OW % 4 == 0 || p.TH >= p.OH) && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
-        !(getenv("QE_EPI_PATCH") && atoi(getenv("QE_EPI_PATCH")) == 0)) {
-        a.epi_patch = 1;
-        lds_e = std::max(lds_e, (size_t)4 * 32 * 36 * 4);
-    }
     // flat kernels with fused re-quantisation: room for the workgroup's byte patch behind the staging image
     size_t lds_f = p.lds;
     if (rq != nullptr && (p.flat || p.flatg)) {

@@ -38,7 +38,6 @@ struct MfmaArgs {
     int ctab;                  // 1: that table is the per-(border class, channel) correction (stage_ctab), 0: prefix rows
     int n_top, n_bot, n_lft, n_rgt;   // output rows / columns whose taps are clipped at each image edge
     unsigned long long *dbg;   // diagnostic builds (-DQE_STAMP) only: per-wave phase cycle sums
-    int epi_patch;             // 1: lane = pixel epilogues turn each 32 x 32 tile through a per-wave LDS patch (16-byte stores)
     // raw operands, used by the flat 1x1 kernel (it builds its epilogue constants itself)
     const uint8_t *w_raw;      // packed OIHW weights as the caller passed them
     const float *w_scale, *w_zero, *x_scale, *bias;
@@ -206,7 +205,7 @@ template <int WM, int WN, int NIW, bool RQ>
 __device__ __forceinline__ void mfma_epilogue_impl(const MfmaArgs &a, v16i (&acc)[NIW], const int (&sxs)[NIW],
                                                    const bool need_sx, const TileGeom g, const int ot,
                                                    const int wm, const int wn, const int col, const int h, const int KK,
-                                                   const int *ptab, const float *ctab, float *patch)
+                                                   const int *ptab, const float *ctab)
 {
     constexpr int MT = 32 * WM;
     const float zxp = a.x_zero[0] - zero_shift(a.x_bits, a.x_sign);
@@ -258,22 +257,7 @@ __device__ __forceinline__ void mfma_epilogue_impl(const MfmaArgs &a, v16i (&acc
 #pragma unroll
         for (int t = 0; t < NIW; ++t) {
             const int q0 = (wn + t * WN) * 32;
-            if (!RQ && patch != nullptr && full_oc && q0 + 32 <= g.NT) {
-                // whole 32 x 32 tile of one image (GI == 1: the tile's pixels are consecutive in every channel row): through
-                // the wave's private 32 x 36 patch and out as FOUR 1 KiB stores of 8 rows x 128 B instead of sixteen 256-byte
-                // ones -- a back-pressured store costs its 500+ cycles of issue per INSTRUCTION, whatever its width
-                // (in-kernel stamps of qe_conv_pwr.hip, round 3).  Same wave writes and reads: LDS order suffices.
-#pragma unroll
-                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + col] = fmaf(al[r], (float)acc[t][r], bi[r]);
-                const int lane = col + 32 * h;
-                const int rrow = lane >> 3, rq4 = lane & 7;
-                float *dst = out_w + (int64_t)rrow * OHW + q0 + 4 * rq4;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float4 o4 = *reinterpret_cast<const float4 *>(patch + (8 * i + rrow) * 36 + 4 * rq4);
-                    *reinterpret_cast<float4 *>(dst + (int64_t)(8 * i) * OHW) = o4;
-                }
-            } else if (full_oc && q0 + 32 <= g.NT) {
+            if (full_oc && q0 + 32 <= g.NT) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     emit(r, (r & 3) + 8 * (r >> 2), t, fmaf(al[r], (float)acc[t][r], bi[r]));
@@ -390,17 +374,9 @@ __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW
                                               const bool need_sx, const TileGeom g, const int ot,
                                               const int wm, const int wn, const int col, const int h, const int KK,
                                               const int *ptab = nullptr,   // LDS copy of this tile's rows of a.ws, or null
-                                              const float *ctab = nullptr, // LDS [border class][MT] correction table, or null
-                                              float *patch = nullptr)      // this wave's 32 x 36 float LDS patch, or null
+                                              const float *ctab = nullptr) // LDS [border class][MT] correction table, or null
 {
-    mfma_epilogue_impl<WM, WN, NIW, RQ>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab, ctab, patch);
-}
-
-// the wave's store patch: the staging LDS is free once the K loop's last barrier has passed (host: a.epi_patch only when
-// the workgroup's LDS holds waves x 32 x 36 floats, GI == 1 and the planes keep 16-byte pieces aligned)
-__device__ __forceinline__ float *epi_patch_ptr(const MfmaArgs &a, void *smem_base, int wave)
-{
-    return a.epi_patch ? reinterpret_cast<float *>(smem_base) + wave * (32 * 36) : nullptr;
+    mfma_epilogue_impl<WM, WN, NIW, RQ>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab, ctab);
 }
 
 // Asymmetric activations (zx' != 0): the border-aware S_w lookups of the epilogue go to an LDS copy of this tile's MT
@@ -725,7 +701,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs
     {
         const float *ctab = stage_ctab<32 * WM>(a, smem, ot, tid, MF_THREADS);
         const int *ptab = ctab ? nullptr : stage_ptab<32 * WM>(a, smem, ot, tid, MF_THREADS);
-        mfma_epilogue<WM, WN, NIW, RQ>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab, ctab, epi_patch_ptr(a, smem, wave));
+        mfma_epilogue<WM, WN, NIW, RQ>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab, ctab);
     }
 #ifdef QE_STAMP
     QE_ST(7);       // epilogue stores issued
@@ -999,8 +975,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_sm2_kernel(const Mfma
     QE_ST(6);
     const float *ctab = stage_ctab<MT>(a, smem, ot, tid, MF_THREADS);
     const int *ptab = ctab ? nullptr : stage_ptab<MT>(a, smem, ot, tid, MF_THREADS);
-    mfma_epilogue<2 * WMS, WN, NTC, RQ>(a, acc0, sxs, need_sx, g, ot, 2 * wms, wn, col, h, KK, ptab, ctab, epi_patch_ptr(a, smem, wave));
-    mfma_epilogue<2 * WMS, WN, NTC, RQ>(a, acc1, sxs, need_sx, g, ot, 2 * wms + 1, wn, col, h, KK, ptab, ctab, epi_patch_ptr(a, smem, wave));
+    mfma_epilogue<2 * WMS, WN, NTC, RQ>(a, acc0, sxs, need_sx, g, ot, 2 * wms, wn, col, h, KK, ptab, ctab);
+    mfma_epilogue<2 * WMS, WN, NTC, RQ>(a, acc1, sxs, need_sx, g, ot, 2 * wms + 1, wn, col, h, KK, ptab, ctab);
 #ifdef QE_STAMP
     QE_ST(7);
     if (a.dbg != nullptr && lane == 0) {
@@ -1447,7 +1423,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_smallic_kernel(const 
         }
     }
 
-    if (a.epi_patch) __syncthreads();   // the store patches reuse the halo image: every wave is done reading it
     int sxs[NIW];
 #pragma unroll
     for (int t = 0; t < NIW; ++t) {
@@ -1462,7 +1437,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_smallic_kernel(const 
     {
         const float *ctab = stage_ctab<32 * WM>(a, reinterpret_cast<uint8_t *>(smem), ot, tid, MF_THREADS);
         const int *ptab = ctab ? nullptr : stage_ptab<32 * WM>(a, reinterpret_cast<uint8_t *>(smem), ot, tid, MF_THREADS);
-        mfma_epilogue<WM, WN, NIW, RQ>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab, ctab, epi_patch_ptr(a, smem, wave));
+        mfma_epilogue<WM, WN, NIW, RQ>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab, ctab);
     }
 }
 

@@ -176,15 +176,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_pwr_kernel(const PwrArgs a
     const float zxp = a.x_zero[0] - (a.x_sign ? 0.0f : 128.0f);
     const float sx = a.x_scale[0];
     const float zw_shift = a.w_sign ? 0.0f : 128.0f;
-    // does any channel of this wave's strips carry zw' != 0 (S_x needed)?  Wave-uniform.
-    bool any_zw = false;
-    if (!a.w_per_tensor) {
-        for (int s = 0; s < n_my; ++s) any_zw |= (a.w_zero[(strip0 + s * WAVES) * 32 + col] - zw_shift) != 0.0f;
-    } else {
-        any_zw = (a.w_zero[0] - zw_shift) != 0.0f;
-    }
-    const bool need_sx = __builtin_amdgcn_ballot_w64(any_zw) != 0ull;
-
     QE_ST(0);   // prologue: requests issued
     // ---- recode the pieces this lane fetched (u ^ 0x80: signed q, or unsigned q - 128), once for all strips --------
     if (n_my > 0) wait_w(std::integral_constant<int, 0>{}); else __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): tile pieces and first weights landed
@@ -255,7 +246,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_pwr_kernel(const PwrArgs a
     // counter: the wait for the weights names the stores issued behind them).
     constexpr int N_YOUNGER = 4 * NRB;
     static_assert(N_YOUNGER <= 63, "vmcnt is a 6-bit counter");
-    auto epilogue = [&](int strip, float e_sw, float e_zw, float e_bi) __attribute__((always_inline)) {
+    auto epilogue = [&](int strip, float e_sw, float e_zw, float e_bi, bool need_sx) __attribute__((always_inline)) {
         const int oc0 = strip * 32;
         {
             // lane col owns channel oc0 + col; the accumulator rows read the constants back from LDS
@@ -264,66 +255,69 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_pwr_kernel(const PwrArgs a
             const float cst = fmaf((float)G::IC * zxp, zwp, -zxp * (float)sw_sum);
             if (h == 0) {
                 tab[col] = sx * e_sw;
-                tab[32 + col] = cst;
-                tab[64 + col] = e_bi;
+                tab[32 + col] = fmaf(sx * e_sw, cst, e_bi);   // out = alpha * (S - zw' S_x) + (alpha * cst + bias)
                 tab[96 + col] = zwp;
             }
         }
         float *out_s = a.out + ((int64_t)n0 * a.OC + oc0) * P + p0;      // wave-uniform
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            // rows 8 gq + 4 h + j, j = 0..3 of the strip <-> registers 4 gq + j
-            const float4 al = *reinterpret_cast<const float4 *>(tab + 8 * gq + 4 * h);
-            const float4 cs = *reinterpret_cast<const float4 *>(tab + 32 + 8 * gq + 4 * h);
-            const float4 bi = *reinterpret_cast<const float4 *>(tab + 64 + 8 * gq + 4 * h);
-            const float alv[4] = {al.x, al.y, al.z, al.w}, csv[4] = {cs.x, cs.y, cs.z, cs.w};
-            const float biv[4] = {bi.x, bi.y, bi.z, bi.w};
-            float zwv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (need_sx) {
-                const float4 zw = *reinterpret_cast<const float4 *>(tab + 96 + 8 * gq + 4 * h);
-                zwv[0] = zw.x; zwv[1] = zw.y; zwv[2] = zw.z; zwv[3] = zw.w;
-            }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int px = 32 * t + col;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float f = (float)acc[t][4 * gq + j] + csv[j];
-                    if (need_sx) f = fmaf(-zwv[j], sxv[t], f);
-                    v[j] = fmaf(alv[j], f, biv[j]);
+    #pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                // rows 8 gq + 4 h + j, j = 0..3 of the strip <-> registers 4 gq + j
+                const float4 al = *reinterpret_cast<const float4 *>(tab + 8 * gq + 4 * h);
+                const float4 bi = *reinterpret_cast<const float4 *>(tab + 32 + 8 * gq + 4 * h);
+                const float alv[4] = {al.x, al.y, al.z, al.w};
+                const float biv[4] = {bi.x, bi.y, bi.z, bi.w};
+                float zwv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (need_sx) {
+                    const float4 zw = *reinterpret_cast<const float4 *>(tab + 96 + 8 * gq + 4 * h);
+                    zwv[0] = zw.x; zwv[1] = zw.y; zwv[2] = zw.z; zwv[3] = zw.w;
                 }
-                if (32 * t + 32 <= TW || px < TW) {           // first term compile-time: only the last column tile is masked
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) patch[(4 * h + j) * TW + px] = v[j];
+    #pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int px = 32 * t + col;
+                    float v[4];
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float f = (float)acc[t][4 * gq + j];
+                        if (need_sx) f = fmaf(-zwv[j], sxv[t], f);
+                        v[j] = fmaf(alv[j], f, biv[j]);
+                    }
+                    if (32 * t + 32 <= TW || px < TW) {           // first term compile-time: only the last column tile is masked
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j) patch[(4 * h + j) * TW + px] = v[j];
+                    }
+                }
+                // read the 8 x TW block back flat and store 16-byte pieces of its rows (one contiguous run when TW == P).
+                // Exactly NRB store instructions per register quad, whatever the tile: wait_w counts on it.
+                float *out_g = out_s + (int64_t)(8 * gq) * P;
+    #pragma unroll
+                for (int k = 0; k < NRB; ++k) {
+                    const float4 o4 = *reinterpret_cast<const float4 *>(patch + 4 * (64 * k + lane));
+                    if (64 * k + 64 <= 8 * G::PPR || 64 * k + lane < 8 * G::PPR) *reinterpret_cast<float4 *>(out_g + rb_off[k]) = o4;
                 }
             }
-            // read the 8 x TW block back flat and store 16-byte pieces of its rows (one contiguous run when TW == P).
-            // Exactly NRB store instructions per register quad, whatever the tile: wait_w counts on it.
-            float *out_g = out_s + (int64_t)(8 * gq) * P;
-#pragma unroll
-            for (int k = 0; k < NRB; ++k) {
-                const float4 o4 = *reinterpret_cast<const float4 *>(patch + 4 * (64 * k + lane));
-                if (64 * k + 64 <= 8 * G::PPR || 64 * k + lane < 8 * G::PPR) *reinterpret_cast<float4 *>(out_g + rb_off[k]) = o4;
-            }
-        }
     };
 
     // strip s + 1's weights are requested, strip s is stored, strip s + 1 is multiplied.  The wait for the weights leaves
     // the strip's 4 NRB stores in flight (vmcnt(4 NRB)): no store acknowledgement is ever waited for.
-    if (need_sx) mma_strip(std::true_type{}); else mma_strip(std::false_type{});
+    // S_x (per-pixel activation sums) is only needed by strips with some zw' != 0 (asymmetric weights): decided per strip
+    // from the zero points that arrived with its weights -- no pass over w_zero in the prologue (a serial chain of
+    // dependent loads in front of the first barrier)
+    bool sx_cur = __builtin_amdgcn_ballot_w64((c_zw - zw_shift) != 0.0f) != 0ull;
+    if (sx_cur) mma_strip(std::true_type{}); else mma_strip(std::false_type{});
     QE_ST(3);   // K loops
     for (int s = 0; s + 1 < n_my; ++s) {
         const float e_sw = c_sw, e_zw = c_zw, e_bi = c_bi;
         load_w(strip0 + (s + 1) * WAVES);
-        epilogue(strip0 + s * WAVES, e_sw, e_zw, e_bi);
+        epilogue(strip0 + s * WAVES, e_sw, e_zw, e_bi, sx_cur);
         QE_ST(4);   // epilogues: conversions, patch round trips, stores issued
         wait_w(std::integral_constant<int, N_YOUNGER>{});
         QE_ST(5);   // wait for the next strip's weights
-        mma_strip(std::false_type{});
+        sx_cur = __builtin_amdgcn_ballot_w64((c_zw - zw_shift) != 0.0f) != 0ull;
+        if (sx_cur) mma_strip(std::true_type{}); else mma_strip(std::false_type{});
         QE_ST(3);
     }
-    epilogue(strip0 + (n_my - 1) * WAVES, c_sw, c_zw, c_bi);
+    epilogue(strip0 + (n_my - 1) * WAVES, c_sw, c_zw, c_bi, sx_cur);
 #ifdef QE_STAMP
     QE_ST(4);
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): stores acknowledged
@@ -460,14 +454,6 @@ __global__ __launch_bounds__(512, 2) void conv_pwrp_kernel(const PwrArgs a)
     const float zxp = a.x_zero[0] - (a.x_sign ? 0.0f : 128.0f);
     const float sx = a.x_scale[0];
     const float zw_shift = a.w_sign ? 0.0f : 128.0f;
-    bool any_zw = false;
-    if (!a.w_per_tensor) {
-        for (int s = 0; s < n_my; ++s) any_zw |= (a.w_zero[(wave + s * WAVES) * 32 + col] - zw_shift) != 0.0f;
-    } else {
-        any_zw = (a.w_zero[0] - zw_shift) != 0.0f;
-    }
-    const bool need_sx = __builtin_amdgcn_ballot_w64(any_zw) != 0ull;
-
     QE_PWRP_WAIT(0);
     if (!a.bias) c_bi = 0.0f;
     patch_x(fix, 0);
@@ -522,7 +508,7 @@ __global__ __launch_bounds__(512, 2) void conv_pwrp_kernel(const PwrArgs a)
             for (int t = 0; t < NT; ++t) sxv[t] = (float)(sxacc[t] + __shfl_xor(sxacc[t], 32));
         }
     };
-    auto epilogue = [&](int tile, int strip, float e_sw, float e_zw, float e_bi) __attribute__((always_inline)) {
+    auto epilogue = [&](int tile, int strip, float e_sw, float e_zw, float e_bi, bool need_sx) __attribute__((always_inline)) {
         const int n0 = tile / a.tiles_per_image;
         const int p0 = (tile - n0 * a.tiles_per_image) * TW;
         const int oc0 = strip * 32;
@@ -532,46 +518,44 @@ __global__ __launch_bounds__(512, 2) void conv_pwrp_kernel(const PwrArgs a)
             const float cst = fmaf((float)G::IC * zxp, zwp, -zxp * (float)sw_sum);
             if (h == 0) {
                 tab[col] = sx * e_sw;
-                tab[32 + col] = cst;
-                tab[64 + col] = e_bi;
+                tab[32 + col] = fmaf(sx * e_sw, cst, e_bi);   // out = alpha * (S - zw' S_x) + (alpha * cst + bias)
                 tab[96 + col] = zwp;
             }
         }
         float *out_s = a.out + ((int64_t)n0 * a.OC + oc0) * P + p0;
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const float4 al = *reinterpret_cast<const float4 *>(tab + 8 * gq + 4 * h);
-            const float4 cs = *reinterpret_cast<const float4 *>(tab + 32 + 8 * gq + 4 * h);
-            const float4 bi = *reinterpret_cast<const float4 *>(tab + 64 + 8 * gq + 4 * h);
-            const float alv[4] = {al.x, al.y, al.z, al.w}, csv[4] = {cs.x, cs.y, cs.z, cs.w};
-            const float biv[4] = {bi.x, bi.y, bi.z, bi.w};
-            float zwv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (need_sx) {
-                const float4 zw = *reinterpret_cast<const float4 *>(tab + 96 + 8 * gq + 4 * h);
-                zwv[0] = zw.x; zwv[1] = zw.y; zwv[2] = zw.z; zwv[3] = zw.w;
-            }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int px = 32 * t + col;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float f = (float)acc[t][4 * gq + j] + csv[j];
-                    if (need_sx) f = fmaf(-zwv[j], sxv[t], f);
-                    v[j] = fmaf(alv[j], f, biv[j]);
+    #pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 al = *reinterpret_cast<const float4 *>(tab + 8 * gq + 4 * h);
+                const float4 bi = *reinterpret_cast<const float4 *>(tab + 32 + 8 * gq + 4 * h);
+                const float alv[4] = {al.x, al.y, al.z, al.w};
+                const float biv[4] = {bi.x, bi.y, bi.z, bi.w};
+                float zwv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (need_sx) {
+                    const float4 zw = *reinterpret_cast<const float4 *>(tab + 96 + 8 * gq + 4 * h);
+                    zwv[0] = zw.x; zwv[1] = zw.y; zwv[2] = zw.z; zwv[3] = zw.w;
                 }
-                if (32 * t + 32 <= TW || px < TW) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) patch[(4 * h + j) * TW + px] = v[j];
+    #pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int px = 32 * t + col;
+                    float v[4];
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float f = (float)acc[t][4 * gq + j];
+                        if (need_sx) f = fmaf(-zwv[j], sxv[t], f);
+                        v[j] = fmaf(alv[j], f, biv[j]);
+                    }
+                    if (32 * t + 32 <= TW || px < TW) {
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j) patch[(4 * h + j) * TW + px] = v[j];
+                    }
+                }
+                float *out_g = out_s + (int64_t)(8 * gq) * P;
+    #pragma unroll
+                for (int k = 0; k < NRB; ++k) {
+                    const float4 o4 = *reinterpret_cast<const float4 *>(patch + 4 * (64 * k + lane));
+                    if (64 * k + 64 <= 8 * G::PPR || 64 * k + lane < 8 * G::PPR) *reinterpret_cast<float4 *>(out_g + rb_off[k]) = o4;
                 }
             }
-            float *out_g = out_s + (int64_t)(8 * gq) * P;
-#pragma unroll
-            for (int k = 0; k < NRB; ++k) {
-                const float4 o4 = *reinterpret_cast<const float4 *>(patch + 4 * (64 * k + lane));
-                if (64 * k + 64 <= 8 * G::PPR || 64 * k + lane < 8 * G::PPR) *reinterpret_cast<float4 *>(out_g + rb_off[k]) = o4;
-            }
-        }
     };
 
     int cur = 0;
@@ -579,14 +563,15 @@ __global__ __launch_bounds__(512, 2) void conv_pwrp_kernel(const PwrArgs a)
         const int nxt = pt + (int)gridDim.x;
         const bool has_next = nxt < n_tiles;
         for (int s = 0; s < n_my; ++s) {
-            if (s == 0 && need_sx) mma_strip(std::true_type{}, cur); else mma_strip(std::false_type{}, cur);
+            const bool sx_cur = __builtin_amdgcn_ballot_w64((c_zw - zw_shift) != 0.0f) != 0ull;   // this strip has asymmetric weights
+            if (sx_cur) mma_strip(std::true_type{}, cur); else mma_strip(std::false_type{}, cur);
             const float e_sw = c_sw, e_zw = c_zw, e_bi = c_bi;
             const bool last = s + 1 == n_my;
             // next tile's pieces, then next strip's weights: both BEFORE this strip's stores, so that the wait below leaves
             // exactly those stores in flight.  A wave with ONE strip keeps its weights: nothing to reload.
             if (last && has_next) fix = issue_x(nxt, cur ^ 1);
             if (n_my > 1) load_w(wave + (last ? 0 : s + 1) * WAVES);
-            epilogue(pt, wave + s * WAVES, e_sw, e_zw, e_bi);
+            epilogue(pt, wave + s * WAVES, e_sw, e_zw, e_bi, sx_cur);
             QE_PWRP_WAIT(4 * NRB);
             if (!a.bias) c_bi = 0.0f;
         }
