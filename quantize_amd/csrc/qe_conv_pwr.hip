@@ -599,7 +599,12 @@ struct PwrPlan {
 // QE_PWR=0 disables the kernel, QE_PWR_GROUPS overrides the channel split (tuning).
 static bool pwr_plan(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w, PwrPlan *pl)
 {
-    if (const char *e = getenv("QE_PWR")) { if (atoi(e) == 0) return false; }
+    // QE_PWR=0: never; QE_PWR=2: every eligible layer; default (1): layers whose planes are ONE tile (14x14), where the tile is
+    // fetched once instead of OC/128 times and every strip leaves as one contiguous run: -20..25 % against the flat kernels
+    // (profiles/r03a_ab_pwr.txt).  On 28x28 / 56x56 planes both kernels sit on the same store rate (+-3 %).
+    int mode = 1;
+    if (const char *e = getenv("QE_PWR")) mode = atoi(e);
+    if (mode == 0) return false;
     if (sh->KH != 1 || sh->KW != 1 || sh->stride != 1 || sh->padding != 0) return false;
     if (x->n_bits != 8 || w->n_bits != 8 || x->n_param != 1) return false;
     if (sh->IC != 64 && sh->IC != 128 && sh->IC != 256) return false;
@@ -608,6 +613,7 @@ static bool pwr_plan(const qe_conv_shape *sh, const qe_qparam *x, const qe_qpara
     // tiles of 224 or 196 pixels that divide the plane (56x56: 14 x 224; 28x28: 4 x 196; 14x14: the plane itself)
     const int tw = (P % 224 == 0) ? 224 : ((P % 196 == 0) ? 196 : 0);
     if (tw == 0) return false;
+    if (mode == 1 && P != tw) return false;
     if ((int64_t)sh->N * sh->IC * P < 16 || (int64_t)sh->OC * P >= (1ll << 29) || (int64_t)sh->IC * P >= (1ll << 31)) return false;
     if ((reinterpret_cast<uintptr_t>(w->data) & 15) != 0 || (reinterpret_cast<uintptr_t>(x->data) & 3) != 0) return false;
     if ((reinterpret_cast<uintptr_t>(w->scale) & 3) != 0) return false;

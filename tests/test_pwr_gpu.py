@@ -50,7 +50,7 @@ def test_pwr_vs_oracle(engine, pwr):
     grid3: that form on THREE workgroups, so each walks many tiles (tile switch, buffer swap, weight reload and the patched
     tail of the tensor in a late tile); 0: kernel disabled."""
     rng = np.random.RandomState(4242)
-    env = {"QE_PWR": "0" if pwr == "0" else "1"}
+    env = {"QE_PWR": "0" if pwr == "0" else "2"}      # 2: every eligible layer (default 1 = whole-plane tiles only)
     if pwr == "grid3":
         env["QE_PWR_GRID"] = "3"
         env["QE_PWR_PERSIST"] = "1"
@@ -78,12 +78,13 @@ def test_pwr_channel_groups(engine, groups):
             case = _random_case(rng, *shp, 8, 0, 8, 1, w_pc=True, a_pc=False, zeros=True, bias=True)
             y, o32, o64 = _run_case(engine, case, via_capi=True)
             _assert_conv_close(y, o64, o32, "groups=%s %s" % (groups, shp), case["fma"])
-    _with_env({"QE_PWR": "1", "QE_PWR_GROUPS": groups}, run)
+    _with_env({"QE_PWR": "2", "QE_PWR_GROUPS": groups}, run)
 
 
-def test_pwr_batch256_independence(engine):
+def test_pwr_batch256_independence(engine, monkeypatch):
     """The batch-256 launch geometry (256 / 1024 / 3584 workgroups): image i of the batched call == the same image alone."""
     import torch
+    monkeypatch.setenv("QE_PWR", "2")
     rng = np.random.RandomState(5)
     for (ic, hw, oc) in [(256, 14, 1024), (128, 28, 512), (64, 56, 256)]:
         n = 256
