@@ -164,6 +164,11 @@ int qe_quantconv2d(const qe_qparam *x, const qe_qparam *w, const float *bias,
  * calls then accept prepared == NULL.  Scratch for the prepared call: qe_quantconv2d_prepared_workspace_bytes().
  * ------------------------------------------------------------------------- */
 size_t qe_conv_prepared_bytes(const qe_conv_shape *shape, int x_bits, int w_bits);
+/* Signature of the prepared tables' layout (0: nothing to prepare).  It depends on the weight tensor's geometry and on
+ * the kernel family the plan picks, NOT on the batch size, and on the image size only where that changes the family:
+ * a caller that keeps prepared buffers per layer keys them on this value, so alternating batch sizes (or image sizes
+ * served by the same family) reuse one buffer instead of re-preparing. */
+uint64_t qe_conv_prepared_layout(const qe_conv_shape *shape, int x_bits, int w_bits);
 size_t qe_quantconv2d_prepared_workspace_bytes(const qe_conv_shape *shape, int x_bits, int w_bits);
 int qe_conv_prepare(const qe_qparam *w, const float *bias, const qe_conv_shape *shape, int x_bits,
                     void *prepared, size_t prepared_bytes, qe_stream_t stream);

@@ -513,12 +513,80 @@ def gen_g6():
     np.savez_compressed(os.path.join(OUT, "g6_linear_module.npz"), **out)
 
 
+def gen_g7():
+    """Module capture: the reference's QuantMultiheadAttention (modelzoo/modules/quantmultiheadattention.py) calibrated,
+    packed (:165-223: q / k / v projection weights and out_proj through tpack), reloaded (:405-432 -> tunpack) and run
+    through its packed forward (:262-...).  Only the separate-projection form (kdim != embed_dim) can be captured: with
+    kdim == embed_dim the reference's own pack() dereferences the None q_proj_weight (AttributeError) -- the ViT blocks
+    therefore have no reference capture, their projections are covered by the QuantLinear fixtures (G5 / G6)."""
+    mm = import_ref_modules()
+    out, index = {}, []
+    torch.manual_seed(17)
+    cfgs = [
+        ("w8a8_sym", 32, 4, 24, 5, 7, 3,
+         dict(n_bits=8, symmetric=True, signed=True, granularity="channel", range={"name": "minmax"}),
+         dict(n_bits=8, symmetric=True, signed=True, granularity="layer", range={"name": "minmax"})),
+        ("w8a8_asym", 48, 6, 40, 6, 6, 2,
+         dict(n_bits=8, symmetric=False, signed=False, granularity="channel", range={"name": "minmax"}),
+         dict(n_bits=8, symmetric=False, signed=False, granularity="layer", range={"name": "minmax"})),
+        ("w4a8_sym", 64, 8, 48, 4, 9, 2,
+         dict(n_bits=4, symmetric=True, signed=True, granularity="channel", range={"name": "minmax"}),
+         dict(n_bits=8, symmetric=True, signed=True, granularity="layer", range={"name": "minmax"})),
+    ]
+    for (name, E, H, KD, L, S, N, w_set, a_set) in cfgs:
+        ref = torch.nn.MultiheadAttention(E, H, kdim=KD, vdim=KD, bias=True)
+
+        def make():
+            return mm.QuantMultiheadAttention(
+                E, H, kdim=KD, vdim=KD, w_setting=dict(w_set), a_setting=dict(a_set),
+                _parameters={k: (v.detach().clone() if v is not None else None) for k, v in ref._parameters.items()},
+                _modules={"out_proj": ref.out_proj})
+
+        q, k, v = torch.randn(L, N, E), torch.randn(S, N, KD), torch.randn(S, N, KD)
+        if not a_set["symmetric"]:
+            q, k, v = torch.relu(q), torch.relu(k), torch.relu(v)
+        m = make()
+        with torch.no_grad():
+            m.calibrating = True
+            m(q, k, v)
+            m.calibrating = False
+            for mod in m.modules():
+                if isinstance(mod, mm.Quantizer):
+                    mod.quant(True)
+            y_sim, _ = m(q, k, v)
+            m.pack()
+            sd = {kk: vv.clone() for kk, vv in m.state_dict().items()}
+            m2 = make()
+            m2.load_state_dict(sd)
+            for mod in m2.modules():
+                if isinstance(mod, mm.Quantizer):
+                    mod.quant(True)
+            y_packed, attn = m2(q, k, v)
+        key = "m_" + name
+        out[key + "_query"], out[key + "_key"], out[key + "_value"] = q.numpy(), k.numpy(), v.numpy()
+        out[key + "_heads"] = np.array([E, H, KD], np.int32)
+        for kk, vv in sd.items():
+            out[key + "_sd_" + kk] = vv.numpy()
+        out[key + "_y_sim"] = y_sim.numpy()
+        out[key + "_y_packed"] = y_packed.numpy()
+        out[key + "_attn"] = attn.numpy()
+        index.append(key)
+        print("G7 %s: max|sim-packed| = %.3g, q_proj_des=%s, out_proj_des=%s" % (
+            name, float((y_sim - y_packed).abs().max()), sd["q_proj_des"].tolist(), sd["out_proj_des"].tolist()))
+    out["index"] = np.array(index)
+    np.savez_compressed(os.path.join(OUT, "g7_mha_module.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if "--only-g7" in sys.argv:      # added in round 3: leaves the earlier fixtures byte for byte as committed
+        gen_g7()
+        sys.exit(0)
     gen_g1()
     gen_g3()
     gen_g4()
     gen_g5()
     gen_g6()
+    gen_g7()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -23,7 +23,7 @@ SYMBOLS = ["qe_error_string", "qe_last_hip_error", "qe_version", "qe_target_arch
            "qe_conv_prepare", "qe_quantconv2d_prepared", "qe_quantize_pack", "qe_quantconv2d_float_input_workspace_bytes",
            "qe_quantconv2d_float_input_ws", "qe_conv_f32_prepare", "qe_quantconv2d_float_input_prepared",
            "qe_quantconv2d_float_input_path", "qe_quantconv2d_requant_path", "qe_quantconv2d_requant_workspace_bytes",
-           "qe_quantconv2d_requant_prepared"]
+           "qe_quantconv2d_requant_prepared", "qe_conv_prepared_layout"]
 
 
 class QeConvShape(ctypes.Structure):
@@ -176,6 +176,18 @@ def qparam(data, n_bits, sign, scale, zero):
 
 def workspace_bytes(sh, x_bits, w_bits):
     return int(lib().qe_quantconv2d_workspace_bytes(ctypes.byref(sh), int(x_bits), int(w_bits)))
+
+
+def reload_env():
+    """Re-read the QE_* tuning knobs: the library snapshots them once per process (qe_common.h env_get); call this after
+    changing one inside a live process (tests, A/B tools).  Not part of the public C ABI."""
+    lib().qe_debug_reload_env()
+
+
+def conv_prepared_layout(sh, x_bits, w_bits):
+    f = lib().qe_conv_prepared_layout
+    f.restype = ctypes.c_uint64
+    return int(f(ctypes.byref(sh), int(x_bits), int(w_bits)))
 
 
 def conv_path(sh, xq, wq):

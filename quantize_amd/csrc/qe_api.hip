@@ -2,6 +2,16 @@
 // error strings, version, and the conv dispatch (generic fp32 vs int8 MFMA).
 #include "qe_common.h"
 
+#include <atomic>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+#include <unistd.h>
+
+extern char **environ;
+
 namespace qe {
 
 struct RequantHost {   // qe_conv_mfma_kernel.hpp
@@ -15,6 +25,41 @@ struct RequantHost {   // qe_conv_mfma_kernel.hpp
 
 thread_local int g_last_hip_error = 0;
 
+namespace {
+struct EnvSnapshot {
+    std::vector<std::pair<std::string, std::string>> kv;
+};
+std::atomic<EnvSnapshot *> g_env{nullptr};
+std::mutex g_env_mutex;
+EnvSnapshot *take_env_snapshot()
+{
+    auto *snap = new EnvSnapshot;
+    for (char **e = environ; e != nullptr && *e != nullptr; ++e) {
+        if (std::strncmp(*e, "QE_", 3) != 0) continue;
+        const char *eq = std::strchr(*e, '=');
+        if (eq == nullptr) continue;
+        snap->kv.emplace_back(std::string(*e, eq - *e), std::string(eq + 1));
+    }
+    return snap;
+}
+}  // namespace
+
+const char *env_get(const char *name)
+{
+    EnvSnapshot *snap = g_env.load(std::memory_order_acquire);
+    if (snap == nullptr) {
+        std::lock_guard<std::mutex> lock(g_env_mutex);
+        snap = g_env.load(std::memory_order_acquire);
+        if (snap == nullptr) {
+            snap = take_env_snapshot();
+            g_env.store(snap, std::memory_order_release);
+        }
+    }
+    for (const auto &kv : snap->kv)
+        if (kv.first == name) return kv.second.c_str();
+    return nullptr;
+}
+
 int launch_conv_generic(bool packed_in, const void *x, const qe_qparam *xq, const qe_qparam *w,
                         const float *bias, const qe_conv_shape *sh, float *out, hipStream_t s);
 
@@ -22,6 +67,7 @@ int launch_conv_generic(bool packed_in, const void *x, const qe_qparam *xq, cons
 bool mfma_conv_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w);
 size_t mfma_conv_workspace_bytes(const qe_conv_shape *sh, int x_bits, int w_bits);
 size_t mfma_conv_prepared_bytes(const qe_conv_shape *sh, int x_bits, int w_bits);
+uint64_t mfma_conv_prepared_layout(const qe_conv_shape *sh, int x_bits, int w_bits);
 int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh,
                      float *out, void *workspace, size_t workspace_bytes, hipStream_t s, int mode, void *prepared,
                      size_t prepared_bytes, const RequantHost *rq = nullptr);
@@ -77,6 +123,14 @@ extern "C" const char *qe_error_string(int status)
 }
 
 extern "C" int qe_last_hip_error(void) { return qe::g_last_hip_error; }
+
+// Not part of the public ABI (absent from include/quant_engine.h): take a fresh snapshot of the QE_* environment knobs.
+// Old snapshots are kept alive (a few hundred bytes each): a concurrent reader may still hold a pointer into one.
+extern "C" void qe_debug_reload_env(void)
+{
+    std::lock_guard<std::mutex> lock(qe::g_env_mutex);
+    qe::g_env.store(qe::take_env_snapshot(), std::memory_order_release);
+}
 extern "C" const char *qe_version(void) { return "quantize_amd 0.1.0"; }
 extern "C" const char *qe_target_arch(void) { return "gfx950"; }
 
@@ -113,6 +167,12 @@ extern "C" size_t qe_conv_prepared_bytes(const qe_conv_shape *shape, int x_bits,
 {
     if (qe::check_shape(shape) != QE_OK) return 0;
     return qe::mfma_conv_prepared_bytes(shape, x_bits, w_bits);
+}
+
+extern "C" uint64_t qe_conv_prepared_layout(const qe_conv_shape *shape, int x_bits, int w_bits)
+{
+    if (qe::check_shape(shape) != QE_OK) return 0;
+    return qe::mfma_conv_prepared_layout(shape, x_bits, w_bits);
 }
 
 extern "C" size_t qe_quantconv2d_prepared_workspace_bytes(const qe_conv_shape *shape, int x_bits, int w_bits)

@@ -23,6 +23,11 @@ inline int hip_fail(hipError_t e) {
 // Kernel launches are followed by hipGetLastError() (the reference never checks).
 #define QE_LAUNCH_CHECK() QE_HIP_TRY(hipGetLastError())
 
+// Tuning knobs (QE_* environment variables) are read ONCE per process into a snapshot (a conv call used to make 18 getenv
+// calls); env_get() answers from it.  qe_debug_reload_env() (not part of the public ABI; quantize_amd.capi.reload_env)
+// re-reads the environment -- the test-suite and the A/B tools use it after changing a knob inside a live process.
+const char *env_get(const char *name);
+
 constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kNumCU = 256;        // MI355X
 constexpr int kNumXCD = 8;

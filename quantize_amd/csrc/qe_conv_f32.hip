@@ -653,13 +653,13 @@ static size_t f32_align(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static F32Plan f32_plan(const qe_conv_shape *sh)
 {
     F32Plan p;
-    if (getenv("QE_F32_MFMA") && atoi(getenv("QE_F32_MFMA")) == 0) return p;
+    if (env_get("QE_F32_MFMA") && atoi(env_get("QE_F32_MFMA")) == 0) return p;
     p.OH = (sh->H + 2 * sh->padding - sh->KH) / sh->stride + 1;
     p.OW = (sh->W + 2 * sh->padding - sh->KW) / sh->stride + 1;
     p.KK = sh->KH * sh->KW;
     if (p.OH <= 0 || p.OW <= 0 || sh->N <= 0 || sh->OC <= 0) return p;
     if (sh->W < 4 || p.KK > 64) return p;
-    if (sh->IC <= 4 && sh->KH <= 8 && sh->KW <= 8 && !(getenv("QE_F32_STEM") && atoi(getenv("QE_F32_STEM")) == 0)) {
+    if (sh->IC <= 4 && sh->KH <= 8 && sh->KW <= 8 && !(env_get("QE_F32_STEM") && atoi(env_get("QE_F32_STEM")) == 0)) {
         // the stem: K = kh x [kw][ic]; tile = whole output rows, as many as 448 / 224 pixel slots and 64 KB of LDS hold
         if ((int64_t)sh->IC * sh->H * sh->W >= (1ll << 29) || (int64_t)sh->OC * p.OH * p.OW >= (1ll << 29)) return p;
         p.stem = true;
@@ -690,7 +690,7 @@ static F32Plan f32_plan(const qe_conv_shape *sh)
     p.cfg = sh->OC > 64 ? 0 : 1;
     // 3x3 on 7x7 maps: 64-channel workgroups (0.310 -> 0.247 ms on 512->512; every other layer is faster with 128)
     if (sh->OC > 64 && p.KK == 9 && sh->stride == 1 && p.OH * p.OW <= 64) p.cfg = 1;
-    if (getenv("QE_F32_CFG")) p.cfg = atoi(getenv("QE_F32_CFG")) ? 1 : 0;        // tuning
+    if (env_get("QE_F32_CFG")) p.cfg = atoi(env_get("QE_F32_CFG")) ? 1 : 0;        // tuning
     p.MT = p.cfg == 0 ? 128 : 64;
     const int max_tiles = p.cfg == 0 ? 7 : 8;
     if (p.OW > 32 * max_tiles) return p;
@@ -726,7 +726,7 @@ static F32Plan f32_plan(const qe_conv_shape *sh)
         const int units = p.GI * p.IHT * NQ;
         const size_t gsz = (size_t)p.GI * p.IHT * p.IWP;
         const size_t lds2 = (12 * gsz + F32_TRASH) * 16 + 4 * gsz * 4;
-        const bool ns2_env = !(getenv("QE_F32_NS") && atoi(getenv("QE_F32_NS")) == 1);
+        const bool ns2_env = !(env_get("QE_F32_NS") && atoi(env_get("QE_F32_NS")) == 1);
         if (ns2_env && 4 * units <= F32_THREADS && lds2 <= (size_t)F32_MAX_LDS && p.NG >= 4) { p.NS = 2; p.lds = lds2; p.NG = (p.NG + 1) / 2 * 2; }
     }
     p.wt_bytes = (size_t)p.KK * p.NG * p.OCP * 16 * sizeof(uint16_t);

@@ -481,14 +481,14 @@ int launch_flatd(const qe_qparam *x, const qe_qparam *w, const float *bias, cons
     // layers, +15 % on 2048->512 @7x7 -- halving the activation re-reads does NOT give the -14..-26 % a bytes-through-the-CU
     // model predicts.  On for wide 7x7 layers only; QE_FLATD8=0 | 1 overrides.
     bool w8 = var == 8 && sh->OC >= 1024;
-    if (const char *e8 = getenv("QE_FLATD8")) w8 = atoi(e8) != 0 && sh->OC > 128;
+    if (const char *e8 = env_get("QE_FLATD8")) w8 = atoi(e8) != 0 && sh->OC > 128;
     const int MT = w8 ? 256 : 128;
     a.n_oc_tiles = (sh->OC + MT - 1) / MT;
     if (var == 8) { a.tiles_per_image = 1; a.n_pix_tiles = (sh->N + 3) / 4; }
     else { a.tiles_per_image = (a.P + 32 * var - 1) / (32 * var); a.n_pix_tiles = sh->N * a.tiles_per_image; }
     const int64_t per_xcd = ((int64_t)a.n_pix_tiles + 7) / 8;
     a.chunk = (int)(per_xcd < 1 ? 1 : per_xcd);
-    if (const char *ci = getenv("QE_CHUNK_IMAGES")) {
+    if (const char *ci = env_get("QE_CHUNK_IMAGES")) {
         const int64_t k = (int64_t)atoi(ci) * a.tiles_per_image;
         a.chunk = (int)(k < 1 ? 1 : (k < per_xcd ? k : per_xcd));
     }

@@ -242,7 +242,7 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits, bool
     const int POUT = p.OH * p.OW;
     if (!p.flat && p.KK == 1 && sh->stride == 2 && sh->padding == 0 && x_bits == 8 && p.cfg == 0 && sh->IC >= 64 &&
         (POUT % 4) == 0 && POUT >= 64 && 224 % p.OW == 0 && sh->W >= 16 && (sh->W % 4) == 0 &&
-        !(getenv("QE_FLAT_S2") && atoi(getenv("QE_FLAT_S2")) == 0)) {
+        !(env_get("QE_FLAT_S2") && atoi(env_get("QE_FLAT_S2")) == 0)) {
         const int rt = 224 / p.OW, seg = (sh->W + 15) / 16;
         if (64 * rt * seg <= 8 * MF_THREADS) { p.flat = true; p.s2 = true; }
     }
@@ -250,7 +250,7 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits, bool
     // (conv_mfma_flatg_kernel).  QE_FLATG=0 leaves these layers on the halo kernel.
     if (!p.flat && p.KK == 1 && sh->stride == 1 && sh->padding == 0 && x_bits == 8 && p.cfg == 0 && sh->IC >= 64 &&
         (P + 7) / 8 == 7 && (int64_t)sh->N * sh->IC * P < (1ll << 32) &&
-        !(getenv("QE_FLATG") && atoi(getenv("QE_FLATG")) == 0)) {
+        !(env_get("QE_FLATG") && atoi(env_get("QE_FLATG")) == 0)) {
         const int nch = (sh->IC + 31) / 32;
         p.flatg = true;
         p.IWP = 56;                                   // slots per image (P rounded up to 8)
@@ -281,7 +281,7 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits, bool
             // accumulators small enough for a third workgroup per CU.  Then tile quantisation: a plane of
             // 784 pixels (28x28) wastes 12.5 % of 224- or 128-pixel tiles but only 2 % of 160-pixel ones,
             // so the width with clearly less padding wins.  QE_FLAT_NIW overrides (tuning).
-            const char *ov = getenv("QE_FLAT_NIW");
+            const char *ov = env_get("QE_FLAT_NIW");
             const int forced = ov ? atoi(ov) : 0;
             if (forced == 4 || forced == 5 || forced == 7) tiles = forced;
             else {
@@ -302,9 +302,9 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits, bool
         const int nch = (sh->IC + 31) / 32;
         p.NS = 1;
         int ns_max = 4;
-        if (const char *e = getenv("QE_FLAT_NS")) ns_max = std::max(1, atoi(e));   // tuning knob
+        if (const char *e = env_get("QE_FLAT_NS")) ns_max = std::max(1, atoi(e));   // tuning knob
         // 64 -> 256 @56x56 (write-bound, two chunks in all): one chunk per stage is 3 % faster (r02y_ab_flat_ns.txt)
-        if (!getenv("QE_FLAT_NS") && nch == 2 && sh->OC >= 4 * sh->IC && P >= 3136) ns_max = 1;
+        if (!env_get("QE_FLAT_NS") && nch == 2 && sh->OC >= 4 * sh->IC && P >= 3136) ns_max = 1;
         for (int cand = 4; cand > 1; cand >>= 1)
             if (cand <= ns_max && cand <= nch && (size_t)(32 * cand) * rstr + (size_t)ntp * 4 <= (size_t)MF_MAX_LDS) { p.NS = cand; break; }
         p.lds = std::max((size_t)(32 * p.NS) * rstr, (size_t)4 * 32 * 36 * 4) + (size_t)ntp * 4;
@@ -322,7 +322,7 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits, bool
     // tile that is either 64 channels wide or a whole image; QE_SM2=1 forces it wherever it fits, QE_SM2=0 never.
     // 3x3 / stride 1 / pad 1, 8-bit activations, > 64 output channels, IC % 32 == 0: the LDS-DMA kernel (qe_conv_halod.hip).
     // QE_SM2D=0 keeps the register-staged kernels below.
-    const int sm2d_env = getenv("QE_SM2D") ? atoi(getenv("QE_SM2D")) : QE_SM2D_DEFAULT;   // 1: 8 waves, 2: 4 waves
+    const int sm2d_env = env_get("QE_SM2D") ? atoi(env_get("QE_SM2D")) : QE_SM2D_DEFAULT;   // 1: 8 waves, 2: 4 waves
     if (!p.flat && !p.flatg && !p.smallic && p.KK == 9 && x_bits == 8 && p.cfg == 0 && sm2d_env != 0) {
         int GI, TH, niw;
         size_t lds;
@@ -335,7 +335,7 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits, bool
             if ((int64_t)p.wt_bytes >= (1ll << 31)) { p.sm2d = 0; p.GI = 1; p.TH = 0; }
         }
     }
-    const int sm2_env = getenv("QE_SM2") ? atoi(getenv("QE_SM2")) : -1;
+    const int sm2_env = env_get("QE_SM2") ? atoi(env_get("QE_SM2")) : -1;
     if (!p.sm2d && !p.flat && !p.flatg && !p.smallic && p.KK == 9 && sh->KW == 3 && sh->KH == 3 && x_bits == 8 && p.cfg <= 1 && sm2_env != 0) {
         const int max_px = 32 * (p.cfg == 0 ? 8 : 16);
         int GI = 1;
@@ -375,7 +375,7 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits, bool
         int stem_tiles = max_tiles;
         // 64-channel workgroups (the ResNet stem): 7 column tiles per wave = 4 output rows per tile instead of 2
         // (fewer, larger workgroups: less halo re-read, prologue amortised).  QE_STEM_NIW=4 restores the old tiles.
-        if (p.cfg == 1 && !(getenv("QE_STEM_NIW") && atoi(getenv("QE_STEM_NIW")) == 4) && p.OW <= 32 * 14) {
+        if (p.cfg == 1 && !(env_get("QE_STEM_NIW") && atoi(env_get("QE_STEM_NIW")) == 4) && p.OW <= 32 * 14) {
             p.niw = 7;
             stem_tiles = 14;
         }
@@ -428,7 +428,7 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits, bool
         p.wt_bytes = (size_t)p.KK * p.NG * p.OCP * 16;
         // 3x3, 8-bit activations, 128-channel tiles: the warp-specialised kernel (producer/consumer
         // waves, double-buffered halo image).
-        const char *ws_env = getenv("QE_WS");
+        const char *ws_env = env_get("QE_WS");
         // Measured on ResNet-50 (A/B, tools/ab_env.sh QE_WS): it wins where a workgroup has little MFMA work
         // per stage to hide its own fetch behind (7x7 maps: 0.068 -> 0.052-0.057 ms) and loses 5-15 % on the
         // 14x14 / 28x28 / 56x56 layers, where two resident single-role workgroups overlap each other better
@@ -438,7 +438,7 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits, bool
         const bool ws_on = ws_env ? atoi(ws_env) != 0 : ws_default;
         if (p.KK == 9 && sh->KW == 3 && x_bits == 8 && p.cfg == 0 && p.NS == 1 && ws_on) {
             // stride 1 with padding 1: unpadded LDS rows (conflict-free fragment reads) + lane masks
-            const char *np_env = getenv("QE_WS_NOPAD");
+            const char *np_env = env_get("QE_WS_NOPAD");
             const bool nopad = sh->stride == 1 && sh->padding == 1 && (np_env && atoi(np_env) == 1);   // off by default
             const int iwp = nopad ? sh->W : p.IWP;
             const int gd = nopad ? sh->padding : 0;
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void subsample_x4_kernel(const uint8_t *__rest
 
 static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits, int w_bits)
 {
-    const bool expand = x_bits < 8 && !(getenv("QE_EXPAND") && atoi(getenv("QE_EXPAND")) == 0);
+    const bool expand = x_bits < 8 && !(env_get("QE_EXPAND") && atoi(env_get("QE_EXPAND")) == 0);
     const int xb = expand ? 8 : x_bits;
     // Strided 1x1 (the ResNet downsample branches): gather the sampled pixels once (read every other row, write 1/s^2 of
     // the bytes) and run the stride-1 kernels on the dense tensor, instead of staging 2-4x the needed bytes in every
@@ -550,18 +550,18 @@ static MfmaPlan make_plan(const qe_conv_shape *sh, int x_bits, int w_bits)
     // Measured (rocprofv3, in the stack): 512->1024 @28->14 187 -> 137 us, 1024->2048 @14->7 143 -> 109 us; on
     // 256->512 @56->28 the gather (93 us) costs more than it saves, so output planes above 256 pixels keep the flat
     // kernel's in-kernel stride-2 staging.  QE_SUBSAMPLE=1 forces the gather, =0 disables it.
-    const int sub_env = getenv("QE_SUBSAMPLE") ? atoi(getenv("QE_SUBSAMPLE")) : -1;
+    const int sub_env = env_get("QE_SUBSAMPLE") ? atoi(env_get("QE_SUBSAMPLE")) : -1;
     const int p_out = ((sh->H - 1) / std::max(1, (int)sh->stride) + 1) * ((sh->W - 1) / std::max(1, (int)sh->stride) + 1);
     // 4-bit activations, stride 2: ONE pass reads the even nibbles of the even rows and writes dense 8-bit codes
     // (subsample_x4_kernel) instead of expanding the whole tensor first -- there the gather pays on every plane size
     const bool sub_x4 = x_bits == 4 && expand && sh->stride == 2 && (sh->W % 2) == 0 && ((int64_t)sh->H * sh->W % 2) == 0 &&
-                        !(getenv("QE_SUB_X4") && atoi(getenv("QE_SUB_X4")) == 0);
+                        !(env_get("QE_SUB_X4") && atoi(env_get("QE_SUB_X4")) == 0);
     const bool sub = sh->KH == 1 && sh->KW == 1 && sh->stride > 1 && sh->padding == 0 && xb == 8 && sub_env != 0 &&
                      (sub_env > 0 || p_out <= 256 || sub_x4);
     const qe_conv_shape ds = dense_shape(sh);
     // 4-bit activations on a stride-1 1x1 layer with 128-channel workgroups: the flat kernel unpacks the nibbles in its
     // staging registers (QE_X4=0: expansion pass + 8-bit kernel as for every other sub-8-bit case)
-    if (x_bits == 4 && expand && !sub && !(getenv("QE_X4") && atoi(getenv("QE_X4")) == 0)) {
+    if (x_bits == 4 && expand && !sub && !(env_get("QE_X4") && atoi(env_get("QE_X4")) == 0)) {
         MfmaPlan q = make_plan8(sh, 8, w_bits, true);
         if (q.ok && q.flat && !q.s2 && !q.flatg && q.cfg == 0) {
             q.x4 = true;
@@ -709,6 +709,20 @@ size_t mfma_conv_prepared_bytes(const qe_conv_shape *sh, int x_bits, int w_bits)
     return p.ok ? p.prep_total : 0;
 }
 
+// What the prepared tables of a problem look like: two problems with the same weights and the same signature share one
+// prepared buffer whatever their batch size or image size (0: nothing to prepare).  The prep kernels write
+// Wt[tap][NG][OCP][16] (or the stem's per-row layout), 3 x OCP constants and the OCP x (KH+1)(KW+1) prefix table.
+uint64_t mfma_conv_prepared_layout(const qe_conv_shape *sh, int x_bits, int w_bits)
+{
+    const MfmaPlan p = make_plan(sh, x_bits, w_bits);
+    if (!p.ok || p.prep_total == 0) return 0;
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+    mix(p.smallic ? 1 : 0); mix((uint64_t)p.OCP); mix((uint64_t)p.NG); mix((uint64_t)p.KK); mix((uint64_t)sh->KH); mix((uint64_t)sh->KW);
+    mix((uint64_t)sh->IC); mix((uint64_t)sh->OC); mix((uint64_t)p.prep_total); mix((uint64_t)p.ep_off); mix((uint64_t)p.ws_off);
+    return h | 1ull;
+}
+
 // mode 0: prepare + run (workspace = [prepared part | scratch]); mode 1: prepare only into `prepared`;
 // mode 2: run on a `prepared` buffer filled earlier (workspace = scratch only)
 // rq != nullptr: fused re-quantisation -- the epilogues store 8-bit codes into rq->out instead of fp32 into `out`
@@ -782,7 +796,7 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
             while ((1 << log_nq) < nq) ++log_nq;
             const int units2 = shd.H << log_nq;
             if (sh->stride == 2 && (sh->H % 2) == 0 && (1 << log_nq) == nq && 16 * nq <= 2 * sh->W && units2 <= 256 &&
-                !(getenv("QE_SUB2") && atoi(getenv("QE_SUB2")) == 0)) {
+                !(env_get("QE_SUB2") && atoi(env_get("QE_SUB2")) == 0)) {
                 int log_up = 3;
                 while ((1 << log_up) < units2) ++log_up;
                 const int ppb = (256 >> log_up) * 4;
@@ -832,7 +846,7 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     // (1: 224-pixel tiles, 2: 160-pixel tiles, 4: 7x7 planes); default from the per-layer A/B in DESIGN.md.
     {
         const int var = flatd_variant(sh, x, w);
-        const char *e = getenv("QE_FLATD");
+        const char *e = env_get("QE_FLATD");
         const int mask = e ? atoi(e) : QE_FLATD_DEFAULT;
         const int bit = var == 7 ? 1 : (var == 5 ? 2 : (var == 8 ? 4 : 0));
         if (var != 0 && (mask & bit) && rq == nullptr) return mode == 1 ? QE_OK : launch_flatd(x, w, bias, sh, out, s);
@@ -900,7 +914,7 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     // eighth of the tiles (sum over the ResNet-50 layers 4.13 -> 4.07 ms against single-tile interleaving);
     // QE_CHUNK_IMAGES = k overrides with runs of k images (0: single tiles).
     {
-        const char *ci = getenv("QE_CHUNK_IMAGES");
+        const char *ci = env_get("QE_CHUNK_IMAGES");
         const int k = ci ? atoi(ci) : (1 << 20);
         const int64_t per_xcd = (n_units + 7) / 8;
         a.chunk = (int)std::max<int64_t>(1, std::min<int64_t>(per_xcd, (int64_t)k * a.tiles_h));
@@ -934,7 +948,7 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
         a.n_rgt = clipped_hi(sh->W, sh->padding, sh->KW, sh->stride, p.OW);
         const int ncls = (1 + a.n_top + a.n_bot) * (1 + a.n_lft + a.n_rgt);
         a.ctab = (a.ptab_off != 0 && a.n_top + a.n_bot < p.OH && a.n_lft + a.n_rgt < p.OW &&
-                  ncls <= (sh->KH + 1) * (sh->KW + 1) && !(getenv("QE_CTAB") && atoi(getenv("QE_CTAB")) == 0)) ? 1 : 0;
+                  ncls <= (sh->KH + 1) * (sh->KW + 1) && !(env_get("QE_CTAB") && atoi(env_get("QE_CTAB")) == 0)) ? 1 : 0;
     }
     // flat kernels with fused re-quantisation: room for the workgroup's byte patch behind the staging image
     size_t lds_f = p.lds;

@@ -255,7 +255,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_pwr_kernel(const PwrArgs a
             const float cst = fmaf((float)G::IC * zxp, zwp, -zxp * (float)sw_sum);
             if (h == 0) {
                 tab[col] = sx * e_sw;
-                tab[32 + col] = fmaf(sx * e_sw, cst, e_bi);   // out = alpha * (S - zw' S_x) + (alpha * cst + bias)
+                tab[32 + col] = cst;
+                tab[64 + col] = e_bi;
                 tab[96 + col] = zwp;
             }
         }
@@ -518,7 +519,8 @@ __global__ __launch_bounds__(512, 2) void conv_pwrp_kernel(const PwrArgs a)
             const float cst = fmaf((float)G::IC * zxp, zwp, -zxp * (float)sw_sum);
             if (h == 0) {
                 tab[col] = sx * e_sw;
-                tab[32 + col] = fmaf(sx * e_sw, cst, e_bi);   // out = alpha * (S - zw' S_x) + (alpha * cst + bias)
+                tab[32 + col] = cst;
+                tab[64 + col] = e_bi;
                 tab[96 + col] = zwp;
             }
         }
@@ -603,7 +605,7 @@ static bool pwr_plan(const qe_conv_shape *sh, const qe_qparam *x, const qe_qpara
     // fetched once instead of OC/128 times and every strip leaves as one contiguous run: -20..25 % against the flat kernels
     // (profiles/r03a_ab_pwr.txt).  On 28x28 / 56x56 planes both kernels sit on the same store rate (+-3 %).
     int mode = 1;
-    if (const char *e = getenv("QE_PWR")) mode = atoi(e);
+    if (const char *e = env_get("QE_PWR")) mode = atoi(e);
     if (mode == 0) return false;
     if (sh->KH != 1 || sh->KW != 1 || sh->stride != 1 || sh->padding != 0) return false;
     if (x->n_bits != 8 || w->n_bits != 8 || x->n_param != 1) return false;
@@ -622,10 +624,10 @@ static bool pwr_plan(const qe_conv_shape *sh, const qe_qparam *x, const qe_qpara
     if (sh->OC < 64 * waves) return false;                    // fewer than two strips per wave: the flat kernels' tiling fits better (256 -> 128 @56x56: +19 %)
     int groups = 1;
     const int strips = sh->OC / 32;
-    if (const char *e = getenv("QE_PWR_GROUPS")) { const int v = atoi(e); if (v >= 1 && strips % v == 0) groups = v; }
+    if (const char *e = env_get("QE_PWR_GROUPS")) { const int v = atoi(e); if (v >= 1 && strips % v == 0) groups = v; }
     pl->tw = tw; pl->waves = waves; pl->ks = ks; pl->groups = groups;
     // IC <= 128 with at least one strip for each of 8 waves: the persistent double-buffered form (QE_PWR_PERSIST=0: off)
-    pl->persistent = ks <= 4 && sh->OC >= 256 && groups == 1 && (getenv("QE_PWR_PERSIST") && atoi(getenv("QE_PWR_PERSIST")) == 1);   // opt-in: +13-20 % against one tile per workgroup (profiles/r03d_ab_persist.txt)
+    pl->persistent = ks <= 4 && sh->OC >= 256 && groups == 1 && (env_get("QE_PWR_PERSIST") && atoi(env_get("QE_PWR_PERSIST")) == 1);   // opt-in: +13-20 % against one tile per workgroup (profiles/r03d_ab_persist.txt)
     return true;
 }
 
@@ -651,7 +653,7 @@ int launch_pwr(const qe_qparam *x, const qe_qparam *w, const float *bias, const 
     a.dbg = g_mfma_dbg;
     const int64_t per_xcd = ((int64_t)a.n_pix_tiles + 7) / 8;
     a.chunk = (int)(per_xcd < 1 ? 1 : per_xcd);
-    if (const char *ci = getenv("QE_CHUNK_IMAGES")) {
+    if (const char *ci = env_get("QE_CHUNK_IMAGES")) {
         const int64_t k = (int64_t)atoi(ci) * a.tiles_per_image;
         a.chunk = (int)(k < 1 ? 1 : (k < per_xcd ? k : per_xcd));
     }
@@ -660,7 +662,7 @@ int launch_pwr(const qe_qparam *x, const qe_qparam *w, const float *bias, const 
     if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
     if (pl.persistent) {
         int grid = kNumCU;
-        if (const char *e = getenv("QE_PWR_GRID")) { const int v = atoi(e); if (v >= 1) grid = v; }
+        if (const char *e = env_get("QE_PWR_GRID")) { const int v = atoi(e); if (v >= 1) grid = v; }
         if (grid > a.n_pix_tiles) grid = a.n_pix_tiles;
 #define QE_PWRP_LAUNCH(KSV, TWV)                                                                                           \
     do {                                                                                                                    \

@@ -404,7 +404,7 @@ extern "C" int qe_quantlinear(const qe_qparam *x, const qe_qparam *w, const floa
         // tile width: 256 columns unless that leaves the chip under-filled; QE_LIN_NJ=2|4 overrides (tuning)
         int nj = 4;
         if (((B + LM - 1) / LM) * ((O + 255) / 256) < kNumCU) nj = 2;   // under-filled chip (the ViT head: 8 workgroups): twice as many, half as wide (17.8 -> 11.5 us)
-        if (const char *e = getenv("QE_LIN_NJ")) nj = atoi(e) == 2 ? 2 : 4;
+        if (const char *e = env_get("QE_LIN_NJ")) nj = atoi(e) == 2 ? 2 : 4;
         const int ln = 64 * nj;
         const int64_t blocks = ((B + LM - 1) / LM) * ((O + ln - 1) / ln);
         if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;

@@ -286,7 +286,9 @@ struct PrepEntry {
     TensorKey w, s, z, b;
     bool has_bias = false;
     int x_bits = 0, w_bits = 0, w_sign = 0;
-    qe_conv_shape sh{};
+    qe_conv_shape sh{};        // float-input entries: the problem with N = 0 (the tables do not depend on the batch size)
+    uint64_t layout = 0;       // qe_conv_prepared_layout: what the tables look like -- NOT the batch or image size, so
+                               // alternating batch sizes of one layer share the entry
     torch::Tensor prepared;
     qe_stream_t stream = nullptr;
 };
@@ -418,6 +420,7 @@ torch::Tensor quantconv2d(const torch::Tensor &input, const torch::Tensor &input
     // Prepared weight tables: built once per (weight, scale, zero, bias) tensor set and kept while those tensors live
     // unchanged; later calls run only the convolution (qe_quantconv2d_prepared).  Results are bit-identical.
     const size_t prep_bytes = qe_conv_prepared_bytes(&sh, xd.n_bits, wd.n_bits);
+    const uint64_t prep_layout = qe_conv_prepared_layout(&sh, xd.n_bits, wd.n_bits);
     const bool use_cache = prep_bytes > 0 && qe_quantconv2d_path(&sh, &xq, &wq) == 1 && cacheable(weight) &&
                            cacheable(weight_scale) && cacheable(weight_zero) && (!bias.has_value() || cacheable(bias.value()));
     if (use_cache) {
@@ -430,7 +433,7 @@ torch::Tensor quantconv2d(const torch::Tensor &input, const torch::Tensor &input
                 const bool hit = e.w.matches(weight) && e.s.matches(weight_scale) && e.z.matches(weight_zero) &&
                                  e.has_bias == bias.has_value() && (!e.has_bias || e.b.matches(bias.value())) &&
                                  e.x_bits == xd.n_bits && e.w_bits == wd.n_bits && e.w_sign == wd.sign &&
-                                 std::memcmp(&e.sh, &sh, sizeof(sh) - 0) == 0 && (size_t)e.prepared.numel() == prep_bytes;
+                                 e.layout == prep_layout && (size_t)e.prepared.numel() == prep_bytes;
                 if (hit) { prepared = e.prepared; ++g_prep_hits; }
             }
         }
@@ -444,7 +447,7 @@ torch::Tensor quantconv2d(const torch::Tensor &input, const torch::Tensor &input
             e.w = TensorKey::of(weight); e.s = TensorKey::of(weight_scale); e.z = TensorKey::of(weight_zero);
             e.has_bias = bias.has_value();
             if (e.has_bias) e.b = TensorKey::of(bias.value());
-            e.x_bits = xd.n_bits; e.w_bits = wd.n_bits; e.w_sign = wd.sign; e.sh = sh; e.prepared = prepared;
+            e.x_bits = xd.n_bits; e.w_bits = wd.n_bits; e.w_sign = wd.sign; e.layout = prep_layout; e.prepared = prepared;
             e.stream = current_stream(input);
             std::lock_guard<std::mutex> lock(g_cache_mutex);
             ++g_prep_misses;
@@ -526,6 +529,8 @@ torch::Tensor quantconv2d_float_input(const torch::Tensor &input, const torch::T
     // bf16 MFMA kernel where the problem is eligible (its weight tables are x-independent: cached like the packed
     // operator's), the order-preserving VALU kernel otherwise
     const size_t prep_bytes = qe_quantconv2d_float_input_path(&sh, &wq) == 1 ? qe_quantconv2d_float_input_workspace_bytes(&sh, wd.n_bits) : 0;
+    qe_conv_shape sh_key = sh;
+    sh_key.N = 0;              // the weight tables do not depend on the batch size: alternating batch sizes share the entry
     if (prep_bytes > 0) {
         const bool use_cache = cacheable(weight) && cacheable(weight_scale) && cacheable(weight_zero) &&
                                (!bias.has_value() || cacheable(bias.value()));
@@ -538,7 +543,7 @@ torch::Tensor quantconv2d_float_input(const torch::Tensor &input, const torch::T
                 const bool hit = e.w.matches(weight) && e.s.matches(weight_scale) && e.z.matches(weight_zero) &&
                                  e.has_bias == bias.has_value() && (!e.has_bias || e.b.matches(bias.value())) &&
                                  e.x_bits == 32 && e.w_bits == wd.n_bits && e.w_sign == wd.sign &&
-                                 std::memcmp(&e.sh, &sh, sizeof(sh)) == 0 && (size_t)e.prepared.numel() == prep_bytes &&
+                                 std::memcmp(&e.sh, &sh_key, sizeof(sh_key)) == 0 && (size_t)e.prepared.numel() == prep_bytes &&
                                  e.stream == current_stream(input);
                 if (hit) { prepared = e.prepared; ++g_prep_hits; }
             }
@@ -552,7 +557,7 @@ torch::Tensor quantconv2d_float_input(const torch::Tensor &input, const torch::T
                 e.w = TensorKey::of(weight); e.s = TensorKey::of(weight_scale); e.z = TensorKey::of(weight_zero);
                 e.has_bias = bias.has_value();
                 if (e.has_bias) e.b = TensorKey::of(bias.value());
-                e.x_bits = 32; e.w_bits = wd.n_bits; e.w_sign = wd.sign; e.sh = sh; e.prepared = prepared;
+                e.x_bits = 32; e.w_bits = wd.n_bits; e.w_sign = wd.sign; e.sh = sh_key; e.prepared = prepared;
                 e.stream = current_stream(input);
                 std::lock_guard<std::mutex> lock(g_cache_mutex);
                 ++g_prep_misses;

@@ -111,8 +111,8 @@ class PackedConv2d(_PackedBase):
         sh = capi.conv_shape(N, IC, H, W, wd[2], wd[4], wd[5], self.stride, self.padding)
         x = capi.qparam(xq, n_bits, sign, self.a_scale, self._neg_a_zero)
         w = capi.qparam(self.weight, wd[0], wd[1], self.w_scale.reshape(-1), self._neg_w_zero.reshape(-1))
-        key = (n_bits, N, H, W)
-        if getattr(self, "_prep_key", None) != key:      # weights prepared once per problem shape
+        key = (n_bits, capi.conv_prepared_layout(sh, n_bits, wd[0]))
+        if getattr(self, "_prep_key", None) != key:      # weights prepared once per table layout (batch size does not enter)
             self._prepared, self._prep_key = capi.conv_prepare(w, self.bias, sh, n_bits), key
         if consumer is None:
             return capi.quantconv2d_prepared(x, w, self.bias, sh, self._prepared)
@@ -148,3 +148,89 @@ class PackedLinear(_PackedBase):
         else:
             raise ValueError("route must be 'packed' or 'float'")
         return y.reshape(*lead, y.shape[-1])
+
+
+class PackedMultiheadAttention:
+    """A packed QuantMultiheadAttention's forward on the engine (modelzoo/modules/quantmultiheadattention.py:262-...).
+    pack() leaves the q / k / v projection weights and out_proj.weight as packed streams with {q,k,v,out}_proj_{scale,
+    zero,des} beside them and one activation quantiser per input (:165-223); the reference's packed forward dequantises
+    all four and calls F.multi_head_attention_forward.  Here the three input projections run as packed linears (either
+    route of PackedLinear, each with its own activation quantiser and its slice of in_proj_bias), the attention core
+    softmax(Q K^T / sqrt(d)) V stays fp32 torch as in the reference, and out_proj -- whose input has no quantiser in the
+    reference -- takes the fp32 x packed-weight operator (quantlinear_float_input).  Inputs are (L, N, E) / (S, N, kdim)
+    (batch_first=False, the module's default); returns (attn_output, averaged attention weights or None)."""
+
+    def __init__(self, q, k, v, out_weight, out_des, out_scale, out_zero, out_bias, num_heads):
+        self.q, self.k, self.v = q, k, v
+        self.out_weight, self.out_des, self.out_bias = out_weight, out_des, out_bias
+        self.out_scale = out_scale.reshape(-1).contiguous()
+        self._neg_out_zero = (-out_zero).reshape(-1).contiguous()          # kernel convention of the float-input operator
+        self.num_heads = int(num_heads)
+
+    @classmethod
+    def from_state_dict(cls, sd, prefix="", num_heads=1):
+        embed = int(sd[prefix + "q_proj_des"][2])
+        bias = sd.get(prefix + "in_proj_bias")
+
+        def proj(name, i):
+            qmin, qmax = float(sd[prefix + name + "_quantizer.qmin"]), float(sd[prefix + name + "_quantizer.qmax"])
+            a_bits = max(1, (int(round(qmax - qmin))).bit_length())
+            return PackedLinear(weight=sd[prefix + name + "_proj_weight"], w_des=sd[prefix + name + "_proj_des"],
+                                w_scale=sd[prefix + name + "_proj_scale"], w_zero=sd[prefix + name + "_proj_zero"],
+                                bias=None if bias is None else bias[i * embed:(i + 1) * embed].contiguous(),
+                                a_scale=sd[prefix + name + "_quantizer.scale"], a_zero=sd[prefix + name + "_quantizer.zero"],
+                                a_qmin=qmin, a_qmax=qmax, a_bits=a_bits, a_signed=qmin < 0)
+        return cls(proj("q", 0), proj("k", 1), proj("v", 2), sd[prefix + "out_proj.weight"], sd[prefix + "out_proj_des"],
+                   sd[prefix + "out_proj_scale"], sd[prefix + "out_proj_zero"], sd.get(prefix + "out_proj.bias"), num_heads)
+
+    def to(self, device):
+        for p in (self.q, self.k, self.v):
+            p.to(device)
+        for name, val in list(vars(self).items()):
+            if torch.is_tensor(val):
+                setattr(self, name, val.to(device))
+        return self
+
+    def __call__(self, query, key, value, route="packed", need_weights=True):
+        L, N, E = query.shape
+        S = key.shape[0]
+        H, d = self.num_heads, E // self.num_heads
+        Q = self.q(query, route).reshape(L, N * H, d).transpose(0, 1)      # (N H, L, d), as F.multi_head_attention_forward splits heads
+        K = self.k(key, route).reshape(S, N * H, d).transpose(0, 1)
+        V = self.v(value, route).reshape(S, N * H, d).transpose(0, 1)
+        attn = torch.softmax(torch.bmm(Q * (float(d) ** -0.5), K.transpose(1, 2)), dim=-1)
+        ctx = torch.bmm(attn, V).transpose(0, 1).reshape(L * N, E).contiguous()
+        out = quantlinear_forward(ctx, (self.out_weight, self.out_des, self.out_scale, self._neg_out_zero), self.out_bias)
+        return out.reshape(L, N, E), (attn.reshape(N, H, L, S).mean(dim=1) if need_weights else None)
+
+
+def from_state_dict(state_dict, conv_geometry=None, num_heads=None):
+    """Every packed layer of a model's state_dict -> {module prefix (no trailing dot): PackedConv2d | PackedLinear |
+    PackedMultiheadAttention}: what the packing loop of runner/ptq.py:106-114 / runner/qat.py:84-92 leaves behind, ready to
+    run on the engine with no reference Python in the process.  A packed conv / linear is recognised by its `w_des` entry
+    (6 fields = conv: n_bits, sign, OC, IC, KH, KW; 4 = linear), an attention block by `q_proj_des`.
+    conv_geometry: {prefix: (stride, padding)} -- geometry is not part of the state_dict; default stride 1, padding
+    (KH - 1) // 2 ("same" for odd kernels).  num_heads: {prefix: heads} (or one int for every attention block)."""
+    conv_geometry = conv_geometry or {}
+    layers = {}
+    for key in state_dict:
+        if key.endswith("w_des"):
+            prefix = key[:-len("w_des")]
+            name = prefix[:-1] if prefix.endswith(".") else prefix
+            des = state_dict[key]
+            if des.numel() == 6:
+                kh = int(des[4])
+                stride, padding = conv_geometry.get(name, (1, (kh - 1) // 2))
+                layers[name] = PackedConv2d.from_state_dict(state_dict, prefix, stride=stride, padding=padding)
+            elif des.numel() == 4:
+                layers[name] = PackedLinear.from_state_dict(state_dict, prefix)
+            else:
+                raise ValueError("%s: a description of %d fields is neither a conv (6) nor a linear (4)" % (key, des.numel()))
+        elif key.endswith("q_proj_des"):
+            prefix = key[:-len("q_proj_des")]
+            name = prefix[:-1] if prefix.endswith(".") else prefix
+            heads = num_heads.get(name) if isinstance(num_heads, dict) else num_heads
+            if heads is None:
+                raise ValueError("%s: num_heads is not part of a state_dict; pass num_heads" % name)
+            layers[name] = PackedMultiheadAttention.from_state_dict(state_dict, prefix, heads)
+    return layers

@@ -51,6 +51,11 @@ def g6():
     return Golden("g6_linear_module.npz")
 
 
+@pytest.fixture(scope="session")
+def g7():
+    return Golden("g7_mha_module.npz")
+
+
 def conv_tolerance(got, exact64, *chains):
     """Parity rule for the fp32 conv result ("fp32-order parity"), with no headroom factor:
 

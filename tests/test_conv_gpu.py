@@ -120,6 +120,7 @@ def _random_case(rng, N, IC, H, W, OC, K, stride, pad, wb, wsgn, ab, asgn, w_pc,
 
 
 def _run_case(engine, case, via_capi=False):
+    capi.reload_env()      # the library snapshots the QE_* knobs once per process; tests flip them between cases
     wp, wd, sw, zw = case["w"]
     w = (_t(wp), _t(wd), _t(sw).reshape(-1, 1, 1, 1), _t(zw).reshape(-1, 1, 1, 1))  # (C,1,1,1) as QuantConv2d stores it
     bias = None if case["bias"] is None else _t(case["bias"])

@@ -34,3 +34,37 @@ def test_linear_state(g6):
     for key in g6.index:
         m = PackedLinear.from_state_dict(_state(g6, key))
         assert m.a_scale.numel() == 1 and m.w_scale.numel() >= 1
+
+
+def test_from_state_dict_builds_every_packed_layer(g4, g6, g7):
+    """quantize_amd.packed.from_state_dict: the packing loop's result (runner/ptq.py:106-114) as a {prefix: Packed*} table --
+    convs and linears recognised by the length of their w_des, attention blocks by q_proj_des, geometry and head counts
+    from the caller's tables (they are not part of a state_dict)."""
+    from quantize_amd.packed import from_state_dict, PackedMultiheadAttention
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    sd = {}
+    ck, lk, mk = g4.index[1], g6.index[0], g7.index[0]
+    for k, v in _state(g4, ck).items():
+        sd["layer1.0.conv2." + k] = v
+    for k, v in _state(g6, lk).items():
+        sd["fc." + k] = v
+    pre = mk + "_sd_"
+    for f in g7._z.files:
+        if f.startswith(pre):
+            sd["blocks.0.attn." + f[len(pre):]] = t(g7._z[f])
+    sd["bn1.running_mean"] = torch.zeros(4)             # unrelated entries are ignored
+    stride, pad = [int(v) for v in g4.get(ck, "stride_pad")]
+    E, H, KD = [int(v) for v in g7.get(mk, "heads")]
+    layers = from_state_dict(sd, conv_geometry={"layer1.0.conv2": (stride, pad)}, num_heads={"blocks.0.attn": H})
+    assert sorted(layers) == ["blocks.0.attn", "fc", "layer1.0.conv2"]
+    conv, fc, mha = layers["layer1.0.conv2"], layers["fc"], layers["blocks.0.attn"]
+    assert isinstance(conv, PackedConv2d) and (conv.stride, conv.padding) == (stride, pad)
+    assert isinstance(fc, PackedLinear) and fc.w_des.numel() == 4
+    assert isinstance(mha, PackedMultiheadAttention) and mha.num_heads == H
+    assert mha.q.bias.numel() == E and torch.equal(mha.k.bias, sd["blocks.0.attn.in_proj_bias"][E:2 * E])
+    assert int(mha.k.w_des[3]) == KD and mha.out_weight.dtype == torch.uint8
+    # default geometry: stride 1, "same" padding for odd kernels
+    assert from_state_dict({k: v for k, v in sd.items() if k.startswith("layer1")})["layer1.0.conv2"].padding == (int(conv.w_des[4]) - 1) // 2
+    import pytest
+    with pytest.raises(ValueError, match="num_heads"):
+        from_state_dict(sd)

@@ -103,3 +103,58 @@ def test_packed_layers_chain_without_fp32_in_between():
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
     assert tuple(out.shape) == (4, 256, 14, 14)
+
+
+def test_resnet_bottleneck_chained_through_call_packed():
+    """A whole ResNet bottleneck (1x1 -> 3x3 -> 1x1, ReLU after the first two, + identity, ReLU) built from a state_dict
+    by packed.from_state_dict and run two ways: (a) layer by layer through the operator route -- every fp32 intermediate
+    is ReLU'd, then quantised and packed by the next layer (what the reference's dataflow does with the engine plugged
+    in); (b) chained through call_packed -- each conv kernel writes the codes of the NEXT layer's activation quantiser,
+    the ReLUs folded into the clamp of the unsigned consumers (no fp32 tensor between the convs).  Same block output, bit
+    for bit."""
+    from quantize_amd.packed import from_state_dict
+    rng = np.random.RandomState(29)
+    sd = {}
+    for name, (ic, oc, k, signed) in {"layer2.1.conv1": (256, 64, 1, True), "layer2.1.conv2": (64, 64, 3, False),
+                                      "layer2.1.conv3": (64, 256, 1, False)}.items():
+        for kk, vv in _synthetic_state(rng, ic, oc, k, signed).items():
+            sd[name + "." + kk] = vv
+    layers = from_state_dict(sd, conv_geometry={"layer2.1.conv1": (1, 0), "layer2.1.conv2": (1, 1), "layer2.1.conv3": (1, 0)})
+    c1, c2, c3 = (layers["layer2.1.conv" + str(i)] for i in (1, 2, 3))
+    x = torch.randn(8, 256, 28, 28, device=DEV)
+    # calibrate the two unsigned (post-ReLU) quantisers from one fp32 pass, as a PTQ run would
+    y1 = torch.relu(c1(x))
+    c2.a_scale = (y1.max() / 255.0).reshape(1)
+    y2 = torch.relu(c2(y1))
+    c3.a_scale = (y2.max() / 255.0).reshape(1)
+    # (a) layer by layer
+    ref = torch.relu(c3(torch.relu(c2(torch.relu(c1(x))))) + x)
+    # (b) chained: quantise once, codes from epilogue to epilogue
+    xq, xd = c1.quantize(x)
+    q2, d2 = c1.call_packed(xq, xd, consumer=c2)
+    q3, d3 = c2.call_packed(q2, d2, consumer=c3)
+    out = torch.relu(c3.call_packed(q3, d3) + x)
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (8, 256, 28, 28)
+    assert torch.equal(out, ref)
+
+
+def test_packed_multihead_attention_on_reference_captures(g7):
+    """PackedMultiheadAttention on the captured runs of the reference's QuantMultiheadAttention (calibrate -> pack() ->
+    state_dict -> reload -> packed forward; separate projection weights, the only form the reference's pack() supports):
+    from the raw fp32 query / key / value and the packed state alone, both routes reproduce the module's output and its
+    averaged attention weights (2e-5 abs on O(1) values: three integer-exact projections, an fp32 softmax, one more
+    projection)."""
+    from quantize_amd.packed import from_state_dict
+    for key in g7.index:
+        pre = key + "_sd_"
+        sd = {f[len(pre):]: _t(g7._z[f]) for f in g7._z.files if f.startswith(pre)}
+        E, H, KD = [int(v) for v in g7.get(key, "heads")]
+        mha = from_state_dict({"attn." + k: v for k, v in sd.items()}, num_heads=H)["attn"]
+        q, k, v = _t(g7.get(key, "query")), _t(g7.get(key, "key")), _t(g7.get(key, "value"))
+        ref, ref_attn = g7.get(key, "y_packed"), g7.get(key, "attn")
+        for route in ("packed", "float"):
+            y, attn = mha(q, k, v, route=route)
+            assert tuple(y.shape) == ref.shape and tuple(attn.shape) == ref_attn.shape
+            assert np.abs(y.cpu().numpy() - ref).max() <= 2e-5, (key, route, float(np.abs(y.cpu().numpy() - ref).max()))
+            assert np.abs(attn.cpu().numpy() - ref_attn).max() <= 2e-5, (key, route)

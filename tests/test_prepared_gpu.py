@@ -103,3 +103,27 @@ def test_module_caches_hit_and_invalidate(engine):
     assert np.abs(y3.cpu().numpy().astype(np.float64) - (2.0 * (ref2 - case["bias"].reshape(1, -1, 1, 1)) + case["bias"].reshape(1, -1, 1, 1))).max() <= 2e-5
     quant_engine.clear_cache()
     assert quant_engine.cache_stats()[4:] == [0, 0]
+
+
+def test_prepared_entry_is_shared_across_batch_sizes(engine):
+    """The prepared tables do not depend on the batch size: a layer called with alternating batch sizes (7, 3, 7, ...)
+    re-uses ONE cache entry (keyed on qe_conv_prepared_layout, not on the whole problem shape) and every result matches
+    the oracle."""
+    import quant_engine
+    quant_engine.clear_cache()
+    rng = np.random.RandomState(91)
+    big = _random_case(rng, 7, 64, 14, 14, 96, 3, 1, 1, 8, 1, 8, 1, w_pc=True, a_pc=False, zeros=False, bias=True)
+    wp, wd, sw, zw = big["w"]
+    xp, xd, sx, zx = big["x"]
+    qx = oracle.tunpack(xp, xd)
+    w = dict(wp=_t(wp), wd=_t(wd), sw=_t(sw).reshape(-1, 1, 1, 1), zw=_t(zw).reshape(-1, 1, 1, 1), b=_t(big["bias"]))
+    sh7 = capi.conv_shape(7, 64, 14, 14, 96, 3, 3, 1, 1)
+    sh3 = capi.conv_shape(3, 64, 14, 14, 96, 3, 3, 1, 1)
+    assert capi.conv_prepared_layout(sh7, 8, 8) == capi.conv_prepared_layout(sh3, 8, 8) != 0
+    misses0 = quant_engine.cache_stats()[3]
+    for n in (7, 3, 7, 3, 1):
+        xpn, xdn = oracle.tpack(qx[:n], 8, 1)
+        y = engine.quantconv2d(_t(xpn), _t(xdn), _t(sx), _t(zx), w["wp"], w["wd"], w["sw"], w["zw"], w["b"], 1, 1)
+        _, ref = oracle.quantconv2d(xpn, xdn, sx, zx, wp, wd, sw, zw, big["bias"], 1, 1, mode="f64", return_f64=True)
+        assert np.abs(y.cpu().numpy().astype(np.float64) - ref).max() <= 1e-5, n
+    assert quant_engine.cache_stats()[3] == misses0 + 1      # prepared once for all five calls

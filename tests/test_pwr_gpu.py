@@ -85,6 +85,7 @@ def test_pwr_batch256_independence(engine, monkeypatch):
     """The batch-256 launch geometry (256 / 1024 / 3584 workgroups): image i of the batched call == the same image alone."""
     import torch
     monkeypatch.setenv("QE_PWR", "2")
+    capi.reload_env()
     rng = np.random.RandomState(5)
     for (ic, hw, oc) in [(256, 14, 1024), (128, 28, 512), (64, 56, 256)]:
         n = 256
