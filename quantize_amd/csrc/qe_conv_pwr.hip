@@ -261,42 +261,45 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_pwr_kernel(const PwrArgs a
             }
         }
         float *out_s = a.out + ((int64_t)n0 * a.OC + oc0) * P + p0;      // wave-uniform
-    #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                // rows 8 gq + 4 h + j, j = 0..3 of the strip <-> registers 4 gq + j
-                const float4 al = *reinterpret_cast<const float4 *>(tab + 8 * gq + 4 * h);
-                const float4 bi = *reinterpret_cast<const float4 *>(tab + 32 + 8 * gq + 4 * h);
-                const float alv[4] = {al.x, al.y, al.z, al.w};
-                const float biv[4] = {bi.x, bi.y, bi.z, bi.w};
-                float zwv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (need_sx) {
-                    const float4 zw = *reinterpret_cast<const float4 *>(tab + 96 + 8 * gq + 4 * h);
-                    zwv[0] = zw.x; zwv[1] = zw.y; zwv[2] = zw.z; zwv[3] = zw.w;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            // rows 8 gq + 4 h + j, j = 0..3 of the strip <-> registers 4 gq + j
+            const float4 al = *reinterpret_cast<const float4 *>(tab + 8 * gq + 4 * h);
+            const float4 cs = *reinterpret_cast<const float4 *>(tab + 32 + 8 * gq + 4 * h);
+            const float4 bi = *reinterpret_cast<const float4 *>(tab + 64 + 8 * gq + 4 * h);
+            const float alv[4] = {al.x, al.y, al.z, al.w}, csv[4] = {cs.x, cs.y, cs.z, cs.w};
+            const float biv[4] = {bi.x, bi.y, bi.z, bi.w};
+            float zwv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (need_sx) {
+                const float4 zw = *reinterpret_cast<const float4 *>(tab + 96 + 8 * gq + 4 * h);
+                zwv[0] = zw.x; zwv[1] = zw.y; zwv[2] = zw.z; zwv[3] = zw.w;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int px = 32 * t + col;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // the flat kernels' operation order exactly (their fused re-quantising epilogue must give the codes
+                    // of quantize_pack on THIS kernel's fp32 output bit for bit: tests/test_requant_gpu.py)
+                    float f = (float)acc[t][4 * gq + j] + csv[j];
+                    if (need_sx) f = fmaf(-zwv[j], sxv[t], f);
+                    v[j] = fmaf(alv[j], f, biv[j]);
                 }
-    #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int px = 32 * t + col;
-                    float v[4];
-    #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float f = (float)acc[t][4 * gq + j];
-                        if (need_sx) f = fmaf(-zwv[j], sxv[t], f);
-                        v[j] = fmaf(alv[j], f, biv[j]);
-                    }
-                    if (32 * t + 32 <= TW || px < TW) {           // first term compile-time: only the last column tile is masked
-    #pragma unroll
-                        for (int j = 0; j < 4; ++j) patch[(4 * h + j) * TW + px] = v[j];
-                    }
-                }
-                // read the 8 x TW block back flat and store 16-byte pieces of its rows (one contiguous run when TW == P).
-                // Exactly NRB store instructions per register quad, whatever the tile: wait_w counts on it.
-                float *out_g = out_s + (int64_t)(8 * gq) * P;
-    #pragma unroll
-                for (int k = 0; k < NRB; ++k) {
-                    const float4 o4 = *reinterpret_cast<const float4 *>(patch + 4 * (64 * k + lane));
-                    if (64 * k + 64 <= 8 * G::PPR || 64 * k + lane < 8 * G::PPR) *reinterpret_cast<float4 *>(out_g + rb_off[k]) = o4;
+                if (32 * t + 32 <= TW || px < TW) {           // first term compile-time: only the last column tile is masked
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) patch[(4 * h + j) * TW + px] = v[j];
                 }
             }
+            // read the 8 x TW block back flat and store 16-byte pieces of its rows (one contiguous run when TW == P).
+            // Exactly NRB store instructions per register quad, whatever the tile: wait_w counts on it.
+            float *out_g = out_s + (int64_t)(8 * gq) * P;
+#pragma unroll
+            for (int k = 0; k < NRB; ++k) {
+                const float4 o4 = *reinterpret_cast<const float4 *>(patch + 4 * (64 * k + lane));
+                if (64 * k + 64 <= 8 * G::PPR || 64 * k + lane < 8 * G::PPR) *reinterpret_cast<float4 *>(out_g + rb_off[k]) = o4;
+            }
+        }
     };
 
     // strip s + 1's weights are requested, strip s is stored, strip s + 1 is multiplied.  The wait for the weights leaves
@@ -525,39 +528,42 @@ __global__ __launch_bounds__(512, 2) void conv_pwrp_kernel(const PwrArgs a)
             }
         }
         float *out_s = a.out + ((int64_t)n0 * a.OC + oc0) * P + p0;
-    #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const float4 al = *reinterpret_cast<const float4 *>(tab + 8 * gq + 4 * h);
-                const float4 bi = *reinterpret_cast<const float4 *>(tab + 32 + 8 * gq + 4 * h);
-                const float alv[4] = {al.x, al.y, al.z, al.w};
-                const float biv[4] = {bi.x, bi.y, bi.z, bi.w};
-                float zwv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (need_sx) {
-                    const float4 zw = *reinterpret_cast<const float4 *>(tab + 96 + 8 * gq + 4 * h);
-                    zwv[0] = zw.x; zwv[1] = zw.y; zwv[2] = zw.z; zwv[3] = zw.w;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const float4 al = *reinterpret_cast<const float4 *>(tab + 8 * gq + 4 * h);
+            const float4 cs = *reinterpret_cast<const float4 *>(tab + 32 + 8 * gq + 4 * h);
+            const float4 bi = *reinterpret_cast<const float4 *>(tab + 64 + 8 * gq + 4 * h);
+            const float alv[4] = {al.x, al.y, al.z, al.w}, csv[4] = {cs.x, cs.y, cs.z, cs.w};
+            const float biv[4] = {bi.x, bi.y, bi.z, bi.w};
+            float zwv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (need_sx) {
+                const float4 zw = *reinterpret_cast<const float4 *>(tab + 96 + 8 * gq + 4 * h);
+                zwv[0] = zw.x; zwv[1] = zw.y; zwv[2] = zw.z; zwv[3] = zw.w;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int px = 32 * t + col;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // the flat kernels' operation order exactly (their fused re-quantising epilogue must give the codes
+                    // of quantize_pack on THIS kernel's fp32 output bit for bit: tests/test_requant_gpu.py)
+                    float f = (float)acc[t][4 * gq + j] + csv[j];
+                    if (need_sx) f = fmaf(-zwv[j], sxv[t], f);
+                    v[j] = fmaf(alv[j], f, biv[j]);
                 }
-    #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int px = 32 * t + col;
-                    float v[4];
-    #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float f = (float)acc[t][4 * gq + j];
-                        if (need_sx) f = fmaf(-zwv[j], sxv[t], f);
-                        v[j] = fmaf(alv[j], f, biv[j]);
-                    }
-                    if (32 * t + 32 <= TW || px < TW) {
-    #pragma unroll
-                        for (int j = 0; j < 4; ++j) patch[(4 * h + j) * TW + px] = v[j];
-                    }
-                }
-                float *out_g = out_s + (int64_t)(8 * gq) * P;
-    #pragma unroll
-                for (int k = 0; k < NRB; ++k) {
-                    const float4 o4 = *reinterpret_cast<const float4 *>(patch + 4 * (64 * k + lane));
-                    if (64 * k + 64 <= 8 * G::PPR || 64 * k + lane < 8 * G::PPR) *reinterpret_cast<float4 *>(out_g + rb_off[k]) = o4;
+                if (32 * t + 32 <= TW || px < TW) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) patch[(4 * h + j) * TW + px] = v[j];
                 }
             }
+            float *out_g = out_s + (int64_t)(8 * gq) * P;
+#pragma unroll
+            for (int k = 0; k < NRB; ++k) {
+                const float4 o4 = *reinterpret_cast<const float4 *>(patch + 4 * (64 * k + lane));
+                if (64 * k + 64 <= 8 * G::PPR || 64 * k + lane < 8 * G::PPR) *reinterpret_cast<float4 *>(out_g + rb_off[k]) = o4;
+            }
+        }
     };
 
     int cur = 0;

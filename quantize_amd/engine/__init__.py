@@ -22,6 +22,7 @@ quantconv2d_float_input = _qe.quantconv2d_float_input
 # extensions of this engine (not part of the reference's facade, hence not in __all__): fused Quantizer + tpack, and
 # the host-side caches of the binding
 quantize_pack = _qe.quantize_pack
+tpack_async = _qe.tpack_async      # tpack without the blocking read-back of the range flag: [packed, des, status]
 clear_cache = _qe.clear_cache
 cache_stats = _qe.cache_stats
 

@@ -166,3 +166,21 @@ def test_global_avgpool_matches_torch():
         ref = x.double().mean(dim=(2, 3))
         assert tuple(y.shape) == shape[:2]
         assert float((y.double() - ref).abs().max()) <= 1e-6
+
+
+def test_tpack_async_returns_the_flag_instead_of_blocking(engine):
+    """quant_engine.tpack_async: same bytes and des as tpack, the range flag handed back as a device tensor (0 = in range)
+    instead of being read back inside the call; an out-of-range input sets it where tpack raises."""
+    import torch
+    x = torch.randint(-8, 8, (3, 5, 7, 9), device="cuda:0").float()
+    p, d = engine.tpack(x, 4, True)
+    pa, da, st = engine.tpack_async(x, 4, True)
+    assert torch.equal(p, pa) and torch.equal(d, da) and st.dtype == torch.int32 and int(st.item()) == 0
+    x[1, 2, 3, 4] = 9.0
+    with pytest.raises(RuntimeError, match="out of range"):
+        engine.tpack(x, 4, True)
+    _, _, st = engine.tpack_async(x, 4, True)
+    assert int(st.item()) != 0
+    # host tensors: the host loop checks first (and raises), the flag is always 0
+    pc, dc, sc = engine.tpack_async(torch.arange(6).float(), 3, False)
+    assert int(sc.item()) == 0 and pc.dtype == torch.uint8
