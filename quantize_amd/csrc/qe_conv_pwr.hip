@@ -43,6 +43,7 @@ struct PwrArgs {
     int n_groups;              // output-channel groups a pixel tile is split over (workgroups per tile)
     int strips_per_group;      // 32-channel strips of one group
     unsigned long long *dbg;   // diagnostic builds (-DQE_STAMP) only: per-wave phase cycle sums
+    int W_in, PIN, OW;         // stride-2 form: input row length, input plane size, output row length (P = output plane)
 };
 
 // NT column tiles of 32 pixel slots (odd), of which the first TW pixels are real: every tile of a launch has the same
@@ -66,7 +67,10 @@ template <int NT, int WAVES, int KS, int TW> struct PwrGeom {
 // instruction, no LDS round trip, 3 vector instructions per element.  In-kernel stamps: under load the epilogues' issue
 // time went UP, 50-57 k -> 78 k cycles per wave on 256 -> 1024 @14x14: a back-pressured store costs its 500+ cycles per
 // INSTRUCTION whatever its width, so the 1 KiB stores of the patch form are worth their LDS round trip.)
-template <int NT, int WAVES, int KS, int TW>
+// S2: 1x1 / stride 2 / pad 0 (the downsample branch of a stage's first block): the tile is TW / OW output rows; its
+// pixels are the even columns of the even input rows, fetched ONCE per tile as 8-byte pieces of those rows (registers,
+// v_perm keeps the even bytes, ds_write_b32) instead of once per 128 output channels by the flat kernel's strided staging.
+template <int NT, int WAVES, int KS, int TW, bool S2 = false>
 __global__ __launch_bounds__(64 * WAVES, 2) void conv_pwr_kernel(const PwrArgs a)
 {
     using G = PwrGeom<NT, WAVES, KS, TW>;
@@ -138,15 +142,54 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_pwr_kernel(const PwrArgs a
     };
     if (n_my > 0) load_w(strip0);
 
+    const int n_xi = (G::XINSTR % WAVES == 0 || wave < G::XINSTR % WAVES) ? PXW : PXW - 1;
+    int fix_i = -1;
+    uint32_t tail_word = 0;
+    if constexpr (S2) {
+        // unit u = tid + THREADS * i <-> (channel c = u / RT, output row r = u % RT of the tile); its input row is W_in bytes =
+        // W_in / 8 pieces, each giving one dword of 4 output pixels.  Every load stays inside its row.
+        constexpr int THREADS = 64 * WAVES;
+        constexpr int MAXP = 8;                               // pieces per row (W_in <= 64)
+        const int RT = TW / a.OW;
+        const int NU = G::IC * RT;
+        const int np = a.W_in >> 3;
+        const int r0 = p0 / a.OW;
+        const uint8_t *xin = a.x + (int64_t)n0 * G::IC * a.PIN;
+        constexpr int UPT = (G::IC * 8 + THREADS - 1) / THREADS;   // RT <= 8
+#pragma unroll
+        for (int i0 = 0; i0 < UPT; i0 += 2) {                 // two units' loads in flight per thread (2 x 16 VGPRs)
+            uint2 d[2][MAXP];
+            int cc[2], rr[2];
+            bool live[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int u = tid + THREADS * (i0 + q);
+                live[q] = (i0 + q) < UPT && u < NU;
+                const int uc = live[q] ? u : 0;
+                cc[q] = uc / RT; rr[q] = uc - cc[q] * RT;
+                const uint8_t *row = xin + (int64_t)cc[q] * a.PIN + (int64_t)(2 * (r0 + rr[q])) * a.W_in;
+#pragma unroll
+                for (int j = 0; j < MAXP; ++j) {
+                    const int jc = j < np ? j : np - 1;       // unconditional loads (clamped), unused pieces dropped below
+                    __builtin_memcpy(&d[q][j], row + 8 * jc, 8);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                uint32_t *dst = reinterpret_cast<uint32_t *>(Xs + cc[q] * RS + rr[q] * a.OW);
+#pragma unroll
+                for (int j = 0; j < MAXP; ++j)
+                    if (live[q] && j < np) dst[j] = __builtin_amdgcn_perm(d[q][j].y, d[q][j].x, 0x06040200u) ^ 0x80808080u;
+            }
+        }
+    } else {
     // ---- the tile: IC x RS bytes by LDS-DMA, slot e = 64 * (wave-instruction q) + lane, q = wave, wave + WAVES, ... ----
     // slot (channel c, j) holds plane bytes [p0 + 16 j, + 16) of channel c.  Only slots of the tensor's LAST plane can
     // reach past its end: pure-garbage slots fetch the tensor's last 16 bytes instead, the one partly valid slot
     // (P % 16 == 4: its 4 valid bytes are the tensor's last dword) is left out of the DMA and written by its lane.
-    const int n_xi = (G::XINSTR % WAVES == 0 || wave < G::XINSTR % WAVES) ? PXW : PXW - 1;
     const int64_t x_total = (int64_t)a.N * G::IC * P;
     const int64_t x_last16 = x_total - 16;
-    const uint32_t tail_word = *reinterpret_cast<const uint32_t *>(a.x + x_total - 4);   // x 4-byte aligned, P % 4 == 0
-    int fix_i = -1;
+    tail_word = *reinterpret_cast<const uint32_t *>(a.x + x_total - 4);   // x 4-byte aligned, P % 4 == 0
 #pragma unroll
     for (int i = 0; i < PXW; ++i) {
         const int e = 64 * (wave + WAVES * i) + lane;
@@ -161,6 +204,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_pwr_kernel(const PwrArgs a
         if (i < n_xi && !skip)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.x + src),
                                              (__attribute__((address_space(3))) void *)(Xs + 1024 * (wave + WAVES * i)), 16, 0, 0);
+    }
+
     }
 
     // ---- per-lane constants of the read-back: piece f = 64 k + lane of the 8 x TW patch -> (row, 16-byte piece) ----
@@ -181,7 +226,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_pwr_kernel(const PwrArgs a
     if (n_my > 0) wait_w(std::integral_constant<int, 0>{}); else __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): tile pieces and first weights landed
 #pragma unroll
     for (int i = 0; i < PXW; ++i) {
-        if (i < n_xi) {
+        if (!S2 && i < n_xi) {
             uint4 *slot = reinterpret_cast<uint4 *>(Xs + 1024 * (wave + WAVES * i) + 16 * lane);
             uint4 v = *slot;
             if (i == fix_i) v.x = tail_word;
@@ -595,13 +640,245 @@ __global__ __launch_bounds__(512, 2) void conv_pwrp_kernel(const PwrArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// 7x7 planes (P = 49: the last stage of a bottleneck network, 512 -> 2048 @7x7).  Same scheme on the small-plane layout of
+// qe_conv_flatd.hip: a tile is GI whole images; image gi, channel c owns a 64-byte LDS row whose four 16-byte slots sit at
+// position j ^ 2 ((c >> 2) & 1), so the 8 rows x 2 pixel groups of a transposed read cover all 64 banks once; a plane is 49
+// contiguous bytes at byte alignment, fetched by LDS-DMA as bytes [16 j, 16 j + 16) (the slack of slot 3 is the next plane's
+// bytes, never stored; only the tensor's last byte has to be patched in by hand).  Column tiles 2 gi, 2 gi + 1 are pixels
+// 0-31 / 32-48 of image gi.  A strip's 32 channels x 49 pixels of one image are ONE contiguous, line-aligned 6,272-byte run
+// of the output: the wave lays the run out in its LDS patch exactly as it stands in memory and copies it flat.
+// ---------------------------------------------------------------------------------------------
+template <int KS, int GI> struct Pwr7Geom {
+    static constexpr int WAVES = 8;
+    static constexpr int IC = 32 * KS;
+    static constexpr int IMG = IC * 64;                      // LDS bytes of one image
+    static constexpr int XBYTES = GI * IMG;
+    static constexpr int XINSTR = XBYTES / 1024;
+    static constexpr int PXW = (XINSTR + WAVES - 1) / WAVES;
+    static constexpr int NT = 2 * GI;
+    static constexpr int TAB = WAVES * 4 * 32 * 4;
+    static constexpr int PATCH = 32 * 49 * 4;
+    static constexpr int NRB = 7;                            // 392 16-byte pieces of a run in rounds of 64 lanes
+    static constexpr int LDS = XBYTES + TAB + WAVES * PATCH;
+};
+
+template <int KS, int GI>
+__global__ __launch_bounds__(512, 2) void conv_pwr7_kernel(const PwrArgs a)
+{
+    using G = Pwr7Geom<KS, GI>;
+    constexpr int WAVES = 8, NT = G::NT, PXW = G::PXW, NRB = G::NRB, P = 49;
+    static_assert(G::XINSTR % WAVES == 0, "every wave issues the same number of tile pieces");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, h = lane >> 5;
+
+    int pt, og;
+    {
+        const int bid = blockIdx.x;
+        const int idx = bid >> 3;
+        const int j = idx / a.n_groups;
+        og = idx - j * a.n_groups;
+        const int c = j / a.chunk;
+        pt = (c * 8 + (bid & 7)) * a.chunk + (j - c * a.chunk);
+    }
+    if (pt >= a.n_pix_tiles) return;
+    const int n0 = pt * GI;                                   // host: N % GI == 0
+
+    uint8_t *Xs = smem;
+    float *tab = reinterpret_cast<float *>(smem + G::XBYTES) + wave * 128;
+    float *patch = reinterpret_cast<float *>(smem + G::XBYTES + G::TAB) + wave * (32 * P);
+
+    const int strip0 = og * a.strips_per_group + wave;
+    const int n_my = (a.strips_per_group - wave + WAVES - 1) / WAVES;
+    v4i wf[KS];
+    float c_sw, c_zw, c_bi;
+    auto load_w = [&](int strip) __attribute__((always_inline)) {
+        const int oc = strip * 32 + col;
+        const float *psw = a.w_scale + (a.w_per_tensor ? 0 : oc);
+        const float *pzw = a.w_zero + (a.w_per_tensor ? 0 : oc);
+        const float *pbi = a.bias ? a.bias + oc : psw;
+        const uint8_t *wl = a.w + (int64_t)oc * G::IC + 16 * h;
+        asm volatile("global_load_dword %0, %3, off\n\tglobal_load_dword %1, %4, off\n\tglobal_load_dword %2, %5, off"
+                     : "=&v"(c_sw), "=&v"(c_zw), "=&v"(c_bi) : "v"(psw), "v"(pzw), "v"(pbi) : "memory");
+#define QE_PWR_LW(K, OFF) if constexpr (KS > K) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(wf[K]) : "v"(wl) : "memory")
+        QE_PWR_LW(0, 0); QE_PWR_LW(1, 32); QE_PWR_LW(2, 64); QE_PWR_LW(3, 96);
+        QE_PWR_LW(4, 128); QE_PWR_LW(5, 160); QE_PWR_LW(6, 192); QE_PWR_LW(7, 224);
+        QE_PWR_LW(8, 256); QE_PWR_LW(9, 288); QE_PWR_LW(10, 320); QE_PWR_LW(11, 352);
+        QE_PWR_LW(12, 384); QE_PWR_LW(13, 416); QE_PWR_LW(14, 448); QE_PWR_LW(15, 480);
+#undef QE_PWR_LW
+    };
+    // one wait statement naming every destination (section 5.7 form (ii)); N = stores issued behind the requests
+#define QE_PWR7_WAIT(N)                                                                                                   \
+    do {                                                                                                                  \
+        if constexpr (KS == 4) asm volatile("s_waitcnt vmcnt(%7)" : "+v"(c_sw), "+v"(c_zw), "+v"(c_bi), "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]) : "i"(N) : "memory"); \
+        else if constexpr (KS == 8) asm volatile("s_waitcnt vmcnt(%11)" : "+v"(c_sw), "+v"(c_zw), "+v"(c_bi), "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(wf[KS - 4]), "+v"(wf[KS - 3]), "+v"(wf[KS - 2]), "+v"(wf[KS - 1]) : "i"(N) : "memory"); \
+        else asm volatile("s_waitcnt vmcnt(%19)" : "+v"(c_sw), "+v"(c_zw), "+v"(c_bi), "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(wf[4]), "+v"(wf[5]), "+v"(wf[6]), "+v"(wf[7]), \
+                          "+v"(wf[KS - 8]), "+v"(wf[KS - 7]), "+v"(wf[KS - 6]), "+v"(wf[KS - 5]), "+v"(wf[KS - 4]), "+v"(wf[KS - 3]), "+v"(wf[KS - 2]), "+v"(wf[KS - 1]) : "i"(N) : "memory"); \
+        if (!a.bias) c_bi = 0.0f;                                                                                        \
+    } while (0)
+    if (n_my > 0) load_w(strip0);
+
+    // ---- the tile by LDS-DMA: slot e = 64 * (wave + 8 i) + lane <-> (image, channel c, position jj) ----
+    const int64_t x_total = (int64_t)a.N * G::IC * P;
+    const int64_t x_last16 = x_total - 16;
+    const uint32_t tail_byte = a.x[x_total - 1];
+    int fix_i = -1;
+#pragma unroll
+    for (int i = 0; i < PXW; ++i) {
+        const int e = 64 * (wave + WAVES * i) + lane;
+        const int img = e / (G::IC * 4);
+        const int r = e - img * (G::IC * 4);
+        const int c = r >> 2, jj = r & 3;
+        const int j = jj ^ (2 * ((c >> 2) & 1));
+        const int64_t src = ((int64_t)(n0 + img) * G::IC + c) * P + 16 * j;
+        const bool skip = src > x_last16;                     // the tensor's last plane, slot 3: one valid byte (the very last)
+        if (skip) fix_i = i;
+        if (!skip)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.x + src),
+                                             (__attribute__((address_space(3))) void *)(Xs + 1024 * (wave + WAVES * i)), 16, 0, 0);
+    }
+
+    const float zxp = a.x_zero[0] - (a.x_sign ? 0.0f : 128.0f);
+    const float sx = a.x_scale[0];
+    const float zw_shift = a.w_sign ? 0.0f : 128.0f;
+
+    if (n_my > 0) QE_PWR7_WAIT(0); else __builtin_amdgcn_s_waitcnt(0x0f70);
+#pragma unroll
+    for (int i = 0; i < PXW; ++i) {
+        uint4 *slot = reinterpret_cast<uint4 *>(Xs + 1024 * (wave + WAVES * i) + 16 * lane);
+        uint4 v = *slot;
+        if (i == fix_i) v = make_uint4(tail_byte, 0u, 0u, 0u);
+        v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
+        *slot = v;
+    }
+    __syncthreads();
+    if (n_my <= 0) return;
+
+    // transposed-read bases (qe_conv_flatd.hip, SMALL): row (16 h + i16 / 2) of a 32-channel step; logical slot 2 tt + ((lane >> 4) & 1)
+    // sits at position slot ^ 2 for rows 4-7 of every 8
+    const int i16 = lane & 15;
+    const int sm_sl = ((lane >> 4) & 1) ^ (2 * (i16 >> 3));
+    const int rowb = (16 * h + (i16 >> 1)) * 64 + 8 * (i16 & 1);
+    const uint8_t *tr_b0 = Xs + rowb + 16 * sm_sl;
+    const uint8_t *tr_b1 = Xs + rowb + 16 * (sm_sl ^ 2);
+
+    float sxv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sxv[t] = 0.0f;
+    v16i acc[NT];
+    int swacc;
+    auto mma_strip = [&](auto sx_tag) __attribute__((always_inline)) {
+        constexpr bool SX = decltype(sx_tag)::value;
+        int sxacc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            sxacc[t] = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0;
+        }
+        swacc = 0;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            v4i wk = wf[k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                wk[j] ^= (int)0x80808080;
+                swacc = __builtin_amdgcn_sdot4(wk[j], 0x01010101, swacc, false);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const uint8_t *src = ((t & 1) ? tr_b1 : tr_b0) + (t >> 1) * G::IMG + k * (32 * 64);
+                const v2i lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(src));
+                const v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(src + 8 * 64));
+                const v4i xf = {lo[0], lo[1], hi[0], hi[1]};
+                if constexpr (SX) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sxacc[t] = __builtin_amdgcn_sdot4(xf[j], 0x01010101, sxacc[t], false);
+                }
+                acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wk, xf, acc[t], 0, 0, 0);
+            }
+        }
+        if constexpr (SX) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) sxv[t] = (float)(sxacc[t] + __shfl_xor(sxacc[t], 32));
+        }
+    };
+
+    auto epilogue = [&](int strip, float e_sw, float e_zw, float e_bi, bool need_sx) __attribute__((always_inline)) {
+        const int oc0 = strip * 32;
+        {
+            const float zwp = e_zw - zw_shift;
+            const int sw_sum = swacc + __shfl_xor(swacc, 32);
+            const float cst = fmaf((float)G::IC * zxp, zwp, -zxp * (float)sw_sum);
+            if (h == 0) {
+                tab[col] = sx * e_sw;
+                tab[32 + col] = cst;
+                tab[64 + col] = e_bi;
+                tab[96 + col] = zwp;
+            }
+        }
+#pragma unroll
+        for (int gi = 0; gi < GI; ++gi) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 al = *reinterpret_cast<const float4 *>(tab + 8 * gq + 4 * h);
+                const float4 cs = *reinterpret_cast<const float4 *>(tab + 32 + 8 * gq + 4 * h);
+                const float4 bi = *reinterpret_cast<const float4 *>(tab + 64 + 8 * gq + 4 * h);
+                const float alv[4] = {al.x, al.y, al.z, al.w}, csv[4] = {cs.x, cs.y, cs.z, cs.w};
+                const float biv[4] = {bi.x, bi.y, bi.z, bi.w};
+                float zwv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (need_sx) {
+                    const float4 zw = *reinterpret_cast<const float4 *>(tab + 96 + 8 * gq + 4 * h);
+                    zwv[0] = zw.x; zwv[1] = zw.y; zwv[2] = zw.z; zwv[3] = zw.w;
+                }
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int t = 2 * gi + tt;
+                    const int px = 32 * tt + col;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        // the flat kernels' operation order (bit-identity with their fused re-quantising epilogue)
+                        float f = (float)acc[t][4 * gq + j] + csv[j];
+                        if (need_sx) f = fmaf(-zwv[j], sxv[t], f);
+                        const float v = fmaf(alv[j], f, biv[j]);
+                        if (tt == 0 || px < P) patch[(8 * gq + 4 * h + j) * P + px] = v;
+                    }
+                }
+            }
+            // the run of image n0 + gi: 32 rows x 49 floats = 392 16-byte pieces, copied flat (NRB stores, the last one 8 lanes wide)
+            float *dst = a.out + ((int64_t)(n0 + gi) * a.OC + oc0) * P;
+#pragma unroll
+            for (int k = 0; k < NRB; ++k) {
+                const float4 o4 = *reinterpret_cast<const float4 *>(patch + 4 * (64 * k + lane));
+                if (64 * k + 64 <= 392 || 64 * k + lane < 392) *reinterpret_cast<float4 *>(dst + 4 * (64 * k + lane)) = o4;
+            }
+        }
+    };
+
+    bool sx_cur = __builtin_amdgcn_ballot_w64((c_zw - zw_shift) != 0.0f) != 0ull;
+    if (sx_cur) mma_strip(std::true_type{}); else mma_strip(std::false_type{});
+    for (int s = 0; s + 1 < n_my; ++s) {
+        const float e_sw = c_sw, e_zw = c_zw, e_bi = c_bi;
+        load_w(strip0 + (s + 1) * WAVES);
+        epilogue(strip0 + s * WAVES, e_sw, e_zw, e_bi, sx_cur);
+        QE_PWR7_WAIT(NRB * GI);                               // the strip's stores stay in flight
+        sx_cur = __builtin_amdgcn_ballot_w64((c_zw - zw_shift) != 0.0f) != 0ull;
+        if (sx_cur) mma_strip(std::true_type{}); else mma_strip(std::false_type{});
+    }
+    epilogue(strip0 + (n_my - 1) * WAVES, c_sw, c_zw, c_bi, sx_cur);
+#undef QE_PWR7_WAIT
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 extern unsigned long long *g_mfma_dbg;   // qe_conv_mfma.hip (diagnostic builds)
 
 struct PwrPlan {
     int tw = 0, waves = 0, ks = 0, groups = 1;
-    bool persistent = false;
+    bool persistent = false, s2 = false;
 };
 
 // QE_PWR=0 disables the kernel, QE_PWR_GROUPS overrides the channel split (tuning).
@@ -609,21 +886,26 @@ static bool pwr_plan(const qe_conv_shape *sh, const qe_qparam *x, const qe_qpara
 {
     // QE_PWR=0: never; QE_PWR=2: every eligible layer; default (1): layers whose planes are ONE tile (14x14), where the tile is
     // fetched once instead of OC/128 times and every strip leaves as one contiguous run: -20..25 % against the flat kernels
-    // (profiles/r03a_ab_pwr.txt).  On 28x28 / 56x56 planes both kernels sit on the same store rate (+-3 %).
+    // (profiles/r03a_ab_pwr.txt), and the stride-2 layers (the strided rows fetched once per tile instead of once per 128
+    // output channels).  On stride-1 28x28 / 56x56 planes both kernels sit on the same store rate (+-3 %).
     int mode = 1;
     if (const char *e = env_get("QE_PWR")) mode = atoi(e);
     if (mode == 0) return false;
-    if (sh->KH != 1 || sh->KW != 1 || sh->stride != 1 || sh->padding != 0) return false;
+    if (sh->KH != 1 || sh->KW != 1 || sh->padding != 0 || (sh->stride != 1 && sh->stride != 2)) return false;
     if (x->n_bits != 8 || w->n_bits != 8 || x->n_param != 1) return false;
     if (sh->IC != 64 && sh->IC != 128 && sh->IC != 256) return false;
     if (sh->OC % 32 != 0 || sh->OC < 128 || sh->N < 1) return false;
-    const int64_t P = (int64_t)sh->H * sh->W;
+    const bool s2 = sh->stride == 2;
+    if (s2 && ((sh->H & 1) || (sh->W & 7) || sh->W > 64 || (env_get("QE_PWR_S2") && atoi(env_get("QE_PWR_S2")) == 0))) return false;
+    const int OH = s2 ? sh->H / 2 : sh->H, OW = s2 ? sh->W / 2 : sh->W;
+    const int64_t P = (int64_t)OH * OW;                       // output plane
     // tiles of 224 or 196 pixels that divide the plane (56x56: 14 x 224; 28x28: 4 x 196; 14x14: the plane itself)
     const int tw = (P % 224 == 0) ? 224 : ((P % 196 == 0) ? 196 : 0);
     if (tw == 0) return false;
-    if (mode == 1 && P != tw) return false;
-    if ((int64_t)sh->N * sh->IC * P < 16 || (int64_t)sh->OC * P >= (1ll << 29) || (int64_t)sh->IC * P >= (1ll << 31)) return false;
-    if ((reinterpret_cast<uintptr_t>(w->data) & 15) != 0 || (reinterpret_cast<uintptr_t>(x->data) & 3) != 0) return false;
+    if (s2 && (tw % OW != 0 || tw / OW > 8)) return false;    // whole output rows per tile
+    if (mode == 1 && !s2 && P != tw) return false;
+    if ((int64_t)sh->N * sh->IC * sh->H * sh->W < 16 || (int64_t)sh->OC * P >= (1ll << 29) || (int64_t)sh->IC * sh->H * sh->W >= (1ll << 31)) return false;
+    if ((reinterpret_cast<uintptr_t>(w->data) & 15) != 0 || (reinterpret_cast<uintptr_t>(x->data) & (s2 ? 7 : 3)) != 0) return false;
     if ((reinterpret_cast<uintptr_t>(w->scale) & 3) != 0) return false;
     const int ks = sh->IC / 32;
     const int waves = ks == 8 ? 8 : 4;                        // IC = 256: 56 KB of tile -> one 8-wave workgroup per CU
@@ -631,27 +913,87 @@ static bool pwr_plan(const qe_conv_shape *sh, const qe_qparam *x, const qe_qpara
     int groups = 1;
     const int strips = sh->OC / 32;
     if (const char *e = env_get("QE_PWR_GROUPS")) { const int v = atoi(e); if (v >= 1 && strips % v == 0) groups = v; }
-    pl->tw = tw; pl->waves = waves; pl->ks = ks; pl->groups = groups;
-    // IC <= 128 with at least one strip for each of 8 waves: the persistent double-buffered form (QE_PWR_PERSIST=0: off)
-    pl->persistent = ks <= 4 && sh->OC >= 256 && groups == 1 && (env_get("QE_PWR_PERSIST") && atoi(env_get("QE_PWR_PERSIST")) == 1);   // opt-in: +13-20 % against one tile per workgroup (profiles/r03d_ab_persist.txt)
+    pl->tw = tw; pl->waves = waves; pl->ks = ks; pl->groups = groups; pl->s2 = s2;
+    // IC <= 128 with at least one strip for each of 8 waves: the persistent double-buffered form (opt-in, QE_PWR_PERSIST=1)
+    pl->persistent = !s2 && ks <= 4 && sh->OC >= 256 && groups == 1 && (env_get("QE_PWR_PERSIST") && atoi(env_get("QE_PWR_PERSIST")) == 1);   // opt-in: +13-20 % against one tile per workgroup (profiles/r03d_ab_persist.txt)
     return true;
+}
+
+// 7x7 planes: 0 = not eligible, else images per tile
+static int pwr7_plan(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w, int *groups)
+{
+    int mode = 1;
+    if (const char *e = env_get("QE_PWR")) mode = atoi(e);
+    if (mode == 0 || (env_get("QE_PWR7") && atoi(env_get("QE_PWR7")) == 0)) return 0;
+    if (sh->KH != 1 || sh->KW != 1 || sh->stride != 1 || sh->padding != 0 || sh->H * sh->W != 49) return 0;
+    if (x->n_bits != 8 || w->n_bits != 8 || x->n_param != 1) return 0;
+    if (sh->IC != 128 && sh->IC != 256 && sh->IC != 512) return 0;
+    const int gi = sh->IC == 512 ? 2 : 4;                     // 64 KB of tile
+    if (sh->OC % 32 != 0 || sh->OC < 512 || sh->N < gi || sh->N % gi != 0) return 0;   // >= 2 strips per wave; whole tiles only
+    if ((int64_t)sh->N * sh->IC * 49 >= (1ll << 31) || (int64_t)sh->OC * 49 >= (1ll << 29)) return 0;
+    if ((reinterpret_cast<uintptr_t>(w->data) & 15) != 0 || (reinterpret_cast<uintptr_t>(x->data) & 15) != 0) return 0;
+    const int tiles = sh->N / gi, strips = sh->OC / 32;
+    int g = 1;
+    while (tiles * g < kNumCU && strips % (2 * g) == 0 && strips / (2 * g) >= 8) g *= 2;   // about one workgroup per CU, >= 1 strip per wave
+    if (const char *e = env_get("QE_PWR_GROUPS")) { const int v = atoi(e); if (v >= 1 && strips % v == 0) g = v; }
+    *groups = g;
+    return gi;
 }
 
 bool pwr_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w)
 {
     PwrPlan pl;
-    return pwr_plan(sh, x, w, &pl);
+    int g;
+    return pwr_plan(sh, x, w, &pl) || pwr7_plan(sh, x, w, &g) != 0;
+}
+
+static int launch_pwr7(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh, float *out, hipStream_t s)
+{
+    int groups = 1;
+    const int gi = pwr7_plan(sh, x, w, &groups);
+    if (gi == 0 || (reinterpret_cast<uintptr_t>(out) & 15) != 0) return QE_ERR_UNSUPPORTED;
+    PwrArgs a;
+    a.x = static_cast<const uint8_t *>(x->data); a.w = static_cast<const uint8_t *>(w->data);
+    a.x_scale = x->scale; a.x_zero = x->zero; a.w_scale = w->scale; a.w_zero = w->zero; a.bias = bias;
+    a.x_sign = x->sign; a.w_sign = w->sign; a.w_per_tensor = (w->n_param == 1);
+    a.out = out; a.N = sh->N; a.IC = sh->IC; a.OC = sh->OC; a.P = 49;
+    a.tiles_per_image = 1;
+    a.n_pix_tiles = sh->N / gi;
+    a.n_groups = groups;
+    a.strips_per_group = sh->OC / 32 / groups;
+    a.dbg = g_mfma_dbg;
+    const int64_t per_xcd = ((int64_t)a.n_pix_tiles + 7) / 8;
+    a.chunk = (int)(per_xcd < 1 ? 1 : per_xcd);
+    const int64_t runs = ((int64_t)a.n_pix_tiles + a.chunk - 1) / a.chunk;
+    const int64_t blocks = (runs + 7) / 8 * a.chunk * 8 * a.n_groups;
+    if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
+#define QE_PWR7_LAUNCH(KSV, GIV)                                                                                            \
+    do {                                                                                                                    \
+        static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pwr7_kernel<KSV, GIV>),           \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, Pwr7Geom<KSV, GIV>::LDS) == hipSuccess; \
+        (void)ok_;                                                                                                          \
+        constexpr size_t lds_ = Pwr7Geom<KSV, GIV>::LDS;                                                                    \
+        hipLaunchKernelGGL((conv_pwr7_kernel<KSV, GIV>), dim3((unsigned)blocks), dim3(512), lds_, s, a);                    \
+    } while (0)
+    if (sh->IC == 512) QE_PWR7_LAUNCH(16, 2); else if (sh->IC == 256) QE_PWR7_LAUNCH(8, 4); else QE_PWR7_LAUNCH(4, 4);
+#undef QE_PWR7_LAUNCH
+    QE_LAUNCH_CHECK();
+    return QE_OK;
 }
 
 int launch_pwr(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh, float *out, hipStream_t s)
 {
+    if (sh->H * sh->W == 49) return launch_pwr7(x, w, bias, sh, out, s);
     PwrPlan pl;
     if (!pwr_plan(sh, x, w, &pl)) return QE_ERR_UNSUPPORTED;
     PwrArgs a;
     a.x = static_cast<const uint8_t *>(x->data); a.w = static_cast<const uint8_t *>(w->data);
     a.x_scale = x->scale; a.x_zero = x->zero; a.w_scale = w->scale; a.w_zero = w->zero; a.bias = bias;
     a.x_sign = x->sign; a.w_sign = w->sign; a.w_per_tensor = (w->n_param == 1);
-    a.out = out; a.N = sh->N; a.IC = sh->IC; a.OC = sh->OC; a.P = sh->H * sh->W;
+    a.out = out; a.N = sh->N; a.IC = sh->IC; a.OC = sh->OC;
+    a.W_in = sh->W; a.PIN = sh->H * sh->W;
+    a.OW = pl.s2 ? sh->W / 2 : sh->W;
+    a.P = pl.s2 ? (sh->H / 2) * (sh->W / 2) : sh->H * sh->W;
     a.tiles_per_image = a.P / pl.tw;
     a.n_pix_tiles = sh->N * a.tiles_per_image;
     a.n_groups = pl.groups;
@@ -684,19 +1026,21 @@ int launch_pwr(const qe_qparam *x, const qe_qparam *w, const float *bias, const 
         QE_LAUNCH_CHECK();
         return QE_OK;
     }
-#define QE_PWR_LAUNCH(WV, KSV, TWV)                                                                                        \
+#define QE_PWR_LAUNCH1(WV, KSV, TWV, S2V)                                                                                  \
     do {                                                                                                                    \
-        static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pwr_kernel<7, WV, KSV, TWV>),     \
+        static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pwr_kernel<7, WV, KSV, TWV, S2V>), \
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, PwrGeom<7, WV, KSV, TWV>::LDS) == hipSuccess; \
         (void)ok_;                                                                                                          \
         constexpr size_t lds_ = PwrGeom<7, WV, KSV, TWV>::LDS;                                                              \
-        hipLaunchKernelGGL((conv_pwr_kernel<7, WV, KSV, TWV>), dim3((unsigned)blocks), dim3(64 * WV), lds_, s, a);          \
+        hipLaunchKernelGGL((conv_pwr_kernel<7, WV, KSV, TWV, S2V>), dim3((unsigned)blocks), dim3(64 * WV), lds_, s, a);     \
     } while (0)
+#define QE_PWR_LAUNCH(WV, KSV, TWV) do { if (pl.s2) QE_PWR_LAUNCH1(WV, KSV, TWV, true); else QE_PWR_LAUNCH1(WV, KSV, TWV, false); } while (0)
     if (pl.tw == 224) {
         if (pl.ks == 2) QE_PWR_LAUNCH(4, 2, 224); else if (pl.ks == 4) QE_PWR_LAUNCH(4, 4, 224); else QE_PWR_LAUNCH(8, 8, 224);
     } else {
         if (pl.ks == 2) QE_PWR_LAUNCH(4, 2, 196); else if (pl.ks == 4) QE_PWR_LAUNCH(4, 4, 196); else QE_PWR_LAUNCH(8, 8, 196);
     }
+#undef QE_PWR_LAUNCH1
 #undef QE_PWR_LAUNCH
     QE_LAUNCH_CHECK();
     return QE_OK;

@@ -21,13 +21,21 @@ SHAPES = [
     (2, 64, 14, 14, 256, 1, 1, 0),
     (2, 128, 28, 28, 512, 1, 1, 0),     # ResNet-50 layer2 expansion: 4 tiles of 196 pixels per plane
     (1, 256, 28, 28, 512, 1, 1, 0),     # the dense form of layer2's downsample branch
-    (3, 256, 56, 56, 512, 1, 2, 0),     # ... and through the stride-2 gather
+    (3, 256, 56, 56, 512, 1, 2, 0),     # ResNet-50 layer2.0.downsample: the stride-2 form (even columns of even rows, fetched once per tile)
+    (2, 64, 56, 56, 256, 1, 2, 0),      # stride 2, IC = 64
+    (1, 128, 56, 56, 512, 1, 2, 0),     # stride 2, IC = 128
+    (2, 64, 28, 64, 256, 1, 2, 0),      # stride 2, 64-byte input rows (8 pieces), 14 x 32 output planes = 2 tiles of 224
     (1, 64, 56, 56, 256, 1, 1, 0),      # ResNet-50 layer1 expansion: 14 tiles of 224 pixels per plane
     (2, 256, 56, 56, 128, 1, 1, 0),     # layer2.0.conv1
     (40, 64, 14, 14, 192, 1, 1, 0),     # more tiles than XCDs
     (1, 128, 28, 16, 128, 1, 1, 0),     # 448-pixel planes: 2 tiles of 224
     (3, 128, 14, 14, 288, 1, 1, 0),     # persistent form, 9 strips on 8 waves (one wave reloads weights, seven keep theirs)
     (5, 64, 28, 28, 512, 1, 1, 0),      # persistent form, 20 tiles, two strips per wave
+    (4, 512, 7, 7, 2048, 1, 1, 0),      # ResNet-50 layer4 expansion: 7x7 planes, 2 images per tile, the tensor's last byte patched
+    (8, 512, 7, 7, 512, 1, 1, 0),       # 7x7, one channel group, two strips per wave
+    (4, 256, 7, 7, 768, 1, 1, 0),       # 7x7, 4 images per tile, 3 strips per wave
+    (8, 128, 7, 7, 1024, 1, 1, 0),      # 7x7, IC = 128
+    (5, 512, 7, 7, 1024, 1, 1, 0),      # odd batch: not a whole number of tiles -> the ring kernel keeps it
 ]
 
 
