@@ -674,6 +674,8 @@ int flatd_variant(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *
 int launch_flatd(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh, float *out, hipStream_t s);
 bool pwr_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w);                          // qe_conv_pwr.hip
 int launch_pwr(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh, float *out, hipStream_t s);
+bool c3_eligible(const MfmaArgs &a);                                                                          // qe_conv_c3.hip
+int launch_c3(const MfmaArgs &a, int64_t n_units, hipStream_t s);
 constexpr int QE_FLATD_DEFAULT = 4;   // 7x7 planes only: -17..-20 % there; the wide variants tie or lose to the register-staged kernels (profiles/r02b_ab_flatd.txt)
 
 bool mfma_conv_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w)
@@ -979,6 +981,7 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
         QE_LAUNCH_CHECK();
         return QE_OK;
     }
+    if (p.sm2 && rq == nullptr && c3_eligible(a)) return launch_c3(a, n_units, s);   // whole-image kernel (qe_conv_c3.hip)
     if (p.sm2) {
         const int units = p.GI * p.IHT * ((sh->W + 3) / 4);
         const int split = units <= 64 ? 4 : (units <= 128 ? 2 : 1);   // channel slices of the staging threads
