@@ -60,6 +60,11 @@ __global__ __launch_bounds__(C3_THREADS, 2) void conv_c3_kernel(const MfmaArgs a
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, h = lane >> 5;
 
+#ifdef QE_STAMP
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = qe_stamp();
+    const unsigned long long tstart = tprev;
+#endif
     int pt, ot, th;
     TileGeom g;
     if (!decode_tile(a, pt, ot, g, th)) return;               // GI == 1, TH == OH: one whole image per tile
@@ -81,6 +86,7 @@ __global__ __launch_bounds__(C3_THREADS, 2) void conv_c3_kernel(const MfmaArgs a
     if (tid < MT) zw_local = (a.ep[a.OCP + ot * MT + tid] != 0.0f) ? 1 : 0;
     const bool need_sx = __syncthreads_or(zw_local) != 0;     // also: the zeroes are in place
 
+    QE_ST(0);   // weight requests, zeroing, first barrier
     // ---- staging: unit u = tid + 512 i <-> (16-channel group, image row, 4-pixel quad), all requested up front -----
     const int NQ = (a.W + 3) >> 2;
     const int HW = a.H * a.W;
@@ -133,7 +139,9 @@ __global__ __launch_bounds__(C3_THREADS, 2) void conv_c3_kernel(const MfmaArgs a
             }
         }
     }
+    QE_ST(1);   // image fetched, transposed, written
     __syncthreads();                                          // the image is complete; from here on every wave runs alone
+    QE_ST(2);   // barrier
 
     // ---- K loop: this wave's strip, 9 taps x KS steps x NIW column tiles --------------------------------------------
     int pixidx[NIW];
@@ -171,6 +179,7 @@ __global__ __launch_bounds__(C3_THREADS, 2) void conv_c3_kernel(const MfmaArgs a
         if (ks + 2 < KS) QE_C3_WAITW(wa);
     }
 
+    QE_ST(4);   // K loop
     // ---- epilogue: the shared lane = pixel epilogue of the 3x3 kernels ----------------------------------------------
     int sxs[NIW];
 #pragma unroll
@@ -184,15 +193,32 @@ __global__ __launch_bounds__(C3_THREADS, 2) void conv_c3_kernel(const MfmaArgs a
     const float *ctab = stage_ctab<MT>(a, smem, ot, tid, C3_THREADS);
     const int *ptab = ctab ? nullptr : stage_ptab<MT>(a, smem, ot, tid, C3_THREADS);
     mfma_epilogue<C3_WAVES, 1, NIW, false>(a, acc, sxs, need_sx, g, ot, wave, 0, col, h, KK, ptab, ctab);
+#ifdef QE_STAMP
+    QE_ST(7);   // epilogue: stores issued
+    if (a.dbg != nullptr && lane == 0) {
+        unsigned long long *o = a.dbg + ((size_t)blockIdx.x * C3_WAVES + wave) * 10;
+        for (int i = 0; i < 8; ++i) o[i] = st[i];
+        o[8] = tprev - tstart;
+        o[9] = tstart;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-// the problem as the sm2 plan describes it (a: geometry, prepared tables) -> eligible?  QE_C3=0 disables the kernel.
+// the problem as the sm2 plan describes it (a: geometry, prepared tables) -> eligible?
+// OPT-IN (QE_C3=1).  Measured (profiles/r03p_ab_c3.txt, r03q_stamp_c3.txt): bit-identical to the sm2 kernel and no faster, 52.0
+// against 49.6-50.2 us on 256 -> 256 @14x14.  The K loop does what it was built for -- 504 MFMAs per wave in 38 k cycles
+// with two waves per SIMD = the matrix pipe 85 % busy, no barrier, no exposed load -- but the layer is ONE round of 256
+// workgroups that all start together: 16 k cycles of fetch + transposes with the matrix pipe idle, 38 k of MFMAs with the
+// memory system idle, 24 k of stores (51 MB at the HBM write rate) with the matrix pipe idle again.  Nothing inside one
+// launch overlaps those three: a wave cannot wait for a weight load without waiting for every older store (vmcnt is
+// in-order), so an overlapped epilogue needs dedicated store waves fed through LDS -- which at one image per CU hides at
+// most the first of two strips' stores (estimate 66 k cycles).
 bool c3_eligible(const MfmaArgs &a)
 {
-    if (const char *e = env_get("QE_C3")) { if (atoi(e) == 0) return false; }
+    if (!(env_get("QE_C3") && atoi(env_get("QE_C3")) == 1)) return false;
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.x_bits != 8) return false;
     if (a.GI != 1 || a.TH != a.OH || a.OH * a.OW > 224 || a.OH * a.OW <= 192) return false;    // one image = 7 column tiles
     if (a.IC != 256 || a.NG != 16 || a.OCP % 256 != 0) return false;
@@ -216,10 +242,11 @@ int launch_c3(const MfmaArgs &a_in, int64_t n_units, hipStream_t s)
     const int64_t runs = (n_units + a.chunk - 1) / a.chunk;
     const int64_t groups = (runs + 7) / 8 * a.chunk;
     const int64_t blocks = groups * 8 * a.n_oc_tiles;
-    if (blocks > 0x7fffffffLL || lds > 160 * 1024) return QE_ERR_UNSUPPORTED;
+    constexpr size_t kMaxLds = 96 * 1024;                    // 16 groups x 256 halo pixels x 16 B + sums + tables = 81 KB
+    if (blocks > 0x7fffffffLL || lds > kMaxLds) return QE_ERR_UNSUPPORTED;
     static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_c3_kernel<8, 7>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-    (void)ok_;
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds) == hipSuccess;
+    if (!ok_) return QE_ERR_HIP;
     hipLaunchKernelGGL((conv_c3_kernel<8, 7>), dim3((unsigned)blocks), dim3(C3_THREADS), lds, s, a);
     QE_LAUNCH_CHECK();
     return QE_OK;
