@@ -430,9 +430,18 @@ def main():
         # the fingerprint of the kernel sources it was measured at and the number is reported only while the sources
         # are still those -- otherwise null, never a stale figure.
         traffic, traffic_tag = None, None
-        tpath = os.path.join(REPO, "profiles", "traffic.json")
-        if os.path.exists(tpath) and not args.layers and N == 256 and args.w_bits == 8 and args.a_bits == 8 \
-                and not args.asymmetric and not args.float_input and not args.fused_requant:
+        slug = None
+        if not args.layers and N == 256 and not args.two_pass and not args.per_call_prepare:
+            if args.float_input and args.w_bits == 8:
+                slug = "_float_input"
+            elif args.fused_requant and args.w_bits == 8 and args.a_bits == 8 and not args.asymmetric:
+                slug = "_fused_requant"
+            elif args.w_bits == 4 and args.a_bits == 4 and not args.asymmetric:
+                slug = "_w4a4"
+            elif args.w_bits == 8 and args.a_bits == 8:
+                slug = "_asymmetric" if args.asymmetric else ""
+        tpath = os.path.join(REPO, "profiles", "traffic%s.json" % (slug or ""))
+        if slug is not None and os.path.exists(tpath):
             try:
                 from quantize_amd.build import source_sha16
                 tj = json.load(open(tpath))
@@ -468,7 +477,7 @@ def main():
             "roofline": {"bound": "hbm",
                          "kernel": ("conv_f32_mfma_kernel + conv_f32_stem_kernel (bf16 x3 MFMA), 53 launches per step, one per layer"
                                     if args.float_input else
-                                    "conv_mfma_{flat,flatg,sm2,ws,smallic,}_kernel + conv_flatd_kernel: one launch per layer, 53 per step (the event span "
+                                    "conv_mfma_{flat,flatg,sm2,ws,smallic,}_kernel + conv_pwr{,7}_kernel + conv_flatd_kernel: one launch per layer, 53 per step (the event span "
                                     "also holds the 2 gather launches of the strided 1x1 layers%s)"
                                     % (" and the 17 weight-prep launches" if args.per_call_prepare else "; weights prepared at set-up")),
                          "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

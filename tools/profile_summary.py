@@ -2,19 +2,24 @@
 """Condense a tools/profile_round.sh run into profiles/<tag>_kernel_stats.csv and profiles/<tag>_traffic.json."""
 import csv, glob, json, os, sys
 out, tag = sys.argv[1], sys.argv[2]
+variant = sys.argv[3] if len(sys.argv) > 3 else ""      # "" = the headline (writes profiles/traffic.json too); else a label
+n_conv = 53
+CONV_KEYS = ("conv_mfma", "conv_flatd", "conv_pwr", "conv_c3", "conv_f32", "conv_generic")
+def is_conv(name):
+    return any(k in name for k in CONV_KEYS) and "prep" not in name
 os.makedirs("profiles", exist_ok=True)
 # kernel stats
 f = glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True)
 if f:
     rows = list(csv.DictReader(open(f[0])))
     with open("profiles/%s_kernel_stats.csv" % tag, "w") as w:
-        w.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline (7 steps incl. warm-up)\n")
+        w.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline %s (7 steps incl. warm-up)\n" % variant)
         w.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
         for r in rows:
             n = r["Name"]
             n = n if len(n) <= 110 else n[:107] + "..."
             w.write('"%s",%s,%s,%s,%s,%s,%s\n' % (n, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]))
-    conv = [r for r in rows if ("conv_mfma" in r["Name"] or "conv_flatd" in r["Name"]) and "prep" not in r["Name"]]
+    conv = [r for r in rows if is_conv(r["Name"])]
     prep = [r for r in rows if "prep" in r["Name"]]
     tot_conv = sum(float(r["TotalDurationNs"]) for r in conv)
     calls_conv = sum(int(r["Calls"]) for r in conv)
@@ -26,7 +31,7 @@ def pmc_sum(kind, counter):
     tot, n = 0.0, 0
     for f in glob.glob(out + "/%s/**/*counter_collection.csv" % kind, recursive=True):
         for r in csv.DictReader(open(f)):
-            if ("conv_mfma" in r["Kernel_Name"] or "conv_flatd" in r["Kernel_Name"]) and "prep" not in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            if is_conv(r["Kernel_Name"]) and r["Counter_Name"] == counter:
                 tot += float(r["Counter_Value"]); n += 1
     return tot, n
 fs, nf = pmc_sum("fetch", "FETCH_SIZE")
@@ -40,8 +45,13 @@ if nf and nw:
     d = {"tag": tag, "source_sha16": source_sha16(), "launches_profiled": nf, "fetch_size_kib_per_launch_raw": fs / nf, "write_size_kib_per_launch": ws / nw,
          "fetch_bytes_per_launch_corrected_x2": fetch_b, "write_bytes_per_launch": write_b,
          "hbm_bytes_per_launch": fetch_b + write_b,
-         "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE) over python bench.py --steps 5 --warmup 2; conv_mfma_* / conv_flatd_* kernels only; "
+         "variant": variant or "headline",
+         "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE) over python3 bench.py --steps 5 --warmup 2 %s; conv_* kernels only (53 per step); " % variant +
                  "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B for 16 B/lane streams)"}
     json.dump(d, open("profiles/%s_traffic.json" % tag, "w"), indent=1)
-    json.dump(d, open("profiles/traffic.json", "w"), indent=1)
+    # the file bench.py reads `roofline.traffic` from: the headline's, or the variant's own
+    slug = {"": "", "--float-input": "_float_input", "--fused-requant": "_fused_requant", "--w-bits 4 --a-bits 4": "_w4a4",
+            "--asymmetric": "_asymmetric"}.get(variant.strip())
+    if slug is not None:
+        json.dump(d, open("profiles/traffic%s.json" % slug, "w"), indent=1)
     print(json.dumps(d))
