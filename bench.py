@@ -67,6 +67,9 @@ def parse_args():
                          "once per layer at set-up (qe_conv_prepare + qe_quantconv2d_prepared: a packed layer's weights do not "
                          "change between forward passes)")
     ap.add_argument("--layers", type=str, default="", help="comma list of layer indices (debug)")
+    ap.add_argument("--microbatches", type=int, default=1,
+                    help="split the batch into M micro-batches, each walking the 53 layers on its own HIP stream (kernels of "
+                         "different micro-batches overlap; not the headline, whose roofline is per launch)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the 53 layer calls as one captured hipGraph instead of launching them one by one "
                          "(measured: no gain, the step is not dispatch-bound: 4.684 vs 4.669 ms)")
@@ -318,7 +321,29 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     sp = ctypes.c_void_p(stream.cuda_stream)
 
+    M = args.microbatches
+    if M > 1:
+        assert N % M == 0 and not args.graph and not args.fused_requant
+        # micro-batch m = its own operands of N / M images per layer and its own stream; `layers` (whole batch) is kept for
+        # the tail and the byte counts
+        mb_layers = [[Layer(i, spc, N // M, dev, args, rank, capi, resnet50, torch) for i, spc in enumerate(specs)] for _ in range(M)]
+        mb_streams = [torch.cuda.Stream(device=dev) for _ in range(M)]
+        mb_sp = [ctypes.c_void_p(st.cuda_stream) for st in mb_streams]
+        mb_ev = [torch.cuda.Event() for _ in range(M)]
+        fork_ev = torch.cuda.Event()
+
     def step():
+        if M > 1:
+            fork_ev.record(stream)
+            for m in range(M):
+                mb_streams[m].wait_event(fork_ev)
+            for i in range(len(specs)):            # interleaved issue order; each stream stays in order
+                for m in range(M):
+                    mb_layers[m][i].run(mb_sp[m])
+            for m in range(M):
+                mb_ev[m].record(mb_streams[m])
+                stream.wait_event(mb_ev[m])
+            return
         for L in layers:
             L.run(sp)
 
@@ -335,6 +360,10 @@ def main():
     # replay it per step (same kernels, arguments and stream order; only the per-launch dispatch gaps go).
     graph = None
     launch_mode = "eager C-ABI calls"
+    if M > 1:
+        launch_mode_mb = "eager C-ABI calls, %d micro-batches of %d images on %d streams" % (M, N // M, M)
+        with torch.cuda.stream(stream):
+            layers[-1].run(sp)                 # the tail's input
     with torch.cuda.stream(stream):
         if args.graph:
             step()                   # first calls outside capture (lazy one-time attribute setup in the library)
@@ -349,6 +378,8 @@ def main():
                 print("hipGraph capture failed (%s); eager launches" % (e,), file=sys.stderr)
                 graph = None
     run_step = graph.replay if graph is not None else step
+    if M > 1:
+        launch_mode = launch_mode_mb
 
     with torch.cuda.stream(stream):
         for _ in range(args.warmup):

@@ -394,8 +394,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_pwr_kernel(const PwrArgs a
 template <int NT, int KS, int TW> struct PwrpGeom {
     static constexpr int WAVES = 8;
     using B = PwrGeom<NT, 8, KS, TW>;
-    static constexpr int XOFF1 = B::XBYTES;
-    static constexpr int TABOFF = 2 * B::XBYTES;
+    static constexpr int NBUF = 3;                           // tile i in use, i + 1 landed, i + 2 in flight
+    static constexpr int TABOFF = NBUF * B::XBYTES;
     static constexpr int PATCHOFF = TABOFF + B::TAB;
     static constexpr int LDS = PATCHOFF + 8 * B::PATCH;
 };
@@ -445,14 +445,16 @@ __global__ __launch_bounds__(512, 2) void conv_pwrp_kernel(const PwrArgs a)
     } while (0)
 
     // ---- tile pieces by LDS-DMA (asm): slot e = 64 * (wave + 8 i) + lane <-> (channel c, 16-byte piece j) ----
-    const int n_xi = (G::XINSTR % WAVES == 0 || wave < G::XINSTR % WAVES) ? PXW : PXW - 1;
     const int64_t x_total = (int64_t)a.N * G::IC * P;
     const int64_t x_last16 = x_total - 16;
     const uint32_t tail_word = *reinterpret_cast<const uint32_t *>(a.x + x_total - 4);
-    int sl_c[PXW], sl_j[PXW];
+    // EVERY wave issues PXW pieces per tile (a wave whose last piece does not exist fetches an earlier one again: same bytes to
+    // the same slot), so that the number of vector-memory operations between two points of the loop is a constant
+    int sl_c[PXW], sl_j[PXW], sl_q[PXW];
 #pragma unroll
     for (int i = 0; i < PXW; ++i) {
-        const int e = 64 * (wave + WAVES * i) + lane;
+        sl_q[i] = (wave + WAVES * i) % G::XINSTR;
+        const int e = 64 * sl_q[i] + lane;
         sl_c[i] = e / (RS / 16);
         sl_j[i] = e - sl_c[i] * (RS / 16);
     }
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(512, 2) void conv_pwrp_kernel(const PwrArgs a)
         int fix = -1;
 #pragma unroll
         for (int i = 0; i < PXW; ++i) {
-            if (i < n_xi) {
+            {
                 int64_t src = ((int64_t)n0 * G::IC + sl_c[i]) * P + p0 + 16 * sl_j[i];
                 bool skip = false;
                 if (src > x_last16) {
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(512, 2) void conv_pwrp_kernel(const PwrArgs a)
                 }
                 const uint64_t live = __builtin_amdgcn_ballot_w64(!skip);
                 const uint8_t *gsrc = a.x + (skip ? x_last16 : src);
-                const uint32_t dst = __builtin_amdgcn_readfirstlane(smem_lds + (uint32_t)(buf * G::XBYTES + 1024 * (wave + WAVES * i)));
+                const uint32_t dst = __builtin_amdgcn_readfirstlane(smem_lds + (uint32_t)(buf * G::XBYTES + 1024 * sl_q[i]));
                 unsigned keep;
                 unsigned long long ex;
                 // `live` is a ballot (a subset of EXEC); s_mov, not s_and: nothing here may write SCC, hipcc keeps a compare
@@ -487,10 +489,11 @@ __global__ __launch_bounds__(512, 2) void conv_pwrp_kernel(const PwrArgs a)
     auto patch_x = [&](int fix, int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PXW; ++i)
-            if (i == fix) *reinterpret_cast<uint32_t *>(smem + buf * G::XBYTES + 1024 * (wave + WAVES * i) + 16 * lane) = tail_word;
+            if (i == fix) *reinterpret_cast<uint32_t *>(smem + buf * G::XBYTES + 1024 * sl_q[i] + 16 * lane) = tail_word;
     };
 
-    int fix = issue_x(pt, 0);
+    int fix = issue_x(pt, 0);                                 // (only the last tile of the tensor ever needs the patch)
+    int fix_next = pt + (int)gridDim.x < n_tiles ? issue_x(pt + (int)gridDim.x, 1) : -1;
     load_w(wave);
 
     uint32_t rb_off[NRB];
@@ -506,6 +509,7 @@ __global__ __launch_bounds__(512, 2) void conv_pwrp_kernel(const PwrArgs a)
     QE_PWRP_WAIT(0);
     if (!a.bias) c_bi = 0.0f;
     patch_x(fix, 0);
+    patch_x(fix_next, 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -611,31 +615,44 @@ __global__ __launch_bounds__(512, 2) void conv_pwrp_kernel(const PwrArgs a)
         }
     };
 
+    // Tile i is multiplied from buffer cur; tile i + 1 landed a tile ago; tile i + 2 is requested before the last strip's
+    // stores of tile i and has a whole tile's time to arrive -- a request joins the CU's memory pipe BEHIND the stores its
+    // eight waves have queued (~200 KB, ~10 us at the HBM rate), so one strip's worth of cover (the first version) stalled
+    // every tile switch.  The wait after the last strip leaves those PXW requests + the strip's stores outstanding.
     int cur = 0;
     for (;;) {
-        const int nxt = pt + (int)gridDim.x;
+        const int nxt = pt + (int)gridDim.x, nxt2 = nxt + (int)gridDim.x;
         const bool has_next = nxt < n_tiles;
+        int fix_next2 = -1;
         for (int s = 0; s < n_my; ++s) {
             const bool sx_cur = __builtin_amdgcn_ballot_w64((c_zw - zw_shift) != 0.0f) != 0ull;   // this strip has asymmetric weights
             if (sx_cur) mma_strip(std::true_type{}, cur); else mma_strip(std::false_type{}, cur);
             const float e_sw = c_sw, e_zw = c_zw, e_bi = c_bi;
             const bool last = s + 1 == n_my;
-            // next tile's pieces, then next strip's weights: both BEFORE this strip's stores, so that the wait below leaves
-            // exactly those stores in flight.  A wave with ONE strip keeps its weights: nothing to reload.
-            if (last && has_next) fix = issue_x(nxt, cur ^ 1);
+            // next strip's weights FIRST (the counted wait below must cover them), then -- on the last strip -- the pieces of
+            // tile i + 2 (or, past the end, of this tile again: a constant count), then this strip's stores
             if (n_my > 1) load_w(wave + (last ? 0 : s + 1) * WAVES);
-            epilogue(pt, wave + s * WAVES, e_sw, e_zw, e_bi, sx_cur);
-            QE_PWRP_WAIT(4 * NRB);
+            if (last) {
+                const int f2 = issue_x(nxt2 < n_tiles ? nxt2 : pt, cur == 0 ? 2 : cur - 1);
+                fix_next2 = nxt2 < n_tiles ? f2 : -1;
+                epilogue(pt, wave + s * WAVES, e_sw, e_zw, e_bi, sx_cur);
+                QE_PWRP_WAIT(4 * NRB + PXW);
+            } else {
+                epilogue(pt, wave + s * WAVES, e_sw, e_zw, e_bi, sx_cur);
+                QE_PWRP_WAIT(4 * NRB);
+            }
             if (!a.bias) c_bi = 0.0f;
         }
         if (!has_next) break;
-        patch_x(fix, cur ^ 1);
+        patch_x(fix_next, cur == 2 ? 0 : cur + 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();     // every wave's pieces of the next tile have landed; nobody reads the old one any more
+        __builtin_amdgcn_s_barrier();     // tile i + 1 is complete for every wave; nobody reads tile i any more
         asm volatile("" ::: "memory");
-        cur ^= 1;
+        cur = cur == 2 ? 0 : cur + 1;
         pt = nxt;
+        fix_next = fix_next2;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the surplus requests of the last tiles must not outlive the workgroup's LDS
 #undef QE_PWRP_WAIT
 }
 
@@ -884,11 +901,13 @@ struct PwrPlan {
 // QE_PWR=0 disables the kernel, QE_PWR_GROUPS overrides the channel split (tuning).
 static bool pwr_plan(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w, PwrPlan *pl)
 {
-    // QE_PWR=0: never; QE_PWR=2: every eligible layer; default (1): layers whose planes are ONE tile (14x14), where the tile is
-    // fetched once instead of OC/128 times and every strip leaves as one contiguous run: -20..25 % against the flat kernels
-    // (profiles/r03a_ab_pwr.txt), and the stride-2 layers (the strided rows fetched once per tile instead of once per 128
-    // output channels).  On stride-1 28x28 / 56x56 planes both kernels sit on the same store rate (+-3 %).
-    int mode = 1;
+    // QE_PWR=0: never; QE_PWR=1: only layers whose planes are ONE tile (14x14: the tile is fetched once instead of OC/128
+    // times and every strip leaves as one contiguous run: -20..25 % against the flat kernels, profiles/r03a_ab_pwr.txt) and
+    // the stride-2 layers (the strided rows fetched once per tile instead of once per 128 output channels); default (2):
+    // every eligible layer -- on stride-1 28x28 / 56x56 planes both kernels sit near the same store rate layer by layer
+    // (+-3 %, inside the noise of isolated timings), over the whole step this form is 1.2 % ahead (three alternating pairs of
+    // 200-step runs on one box, profiles/r03t_ab_pwr_stack.txt)
+    int mode = 2;
     if (const char *e = env_get("QE_PWR")) mode = atoi(e);
     if (mode == 0) return false;
     if (sh->KH != 1 || sh->KW != 1 || sh->padding != 0 || (sh->stride != 1 && sh->stride != 2)) return false;
@@ -915,14 +934,14 @@ static bool pwr_plan(const qe_conv_shape *sh, const qe_qparam *x, const qe_qpara
     if (const char *e = env_get("QE_PWR_GROUPS")) { const int v = atoi(e); if (v >= 1 && strips % v == 0) groups = v; }
     pl->tw = tw; pl->waves = waves; pl->ks = ks; pl->groups = groups; pl->s2 = s2;
     // IC <= 128 with at least one strip for each of 8 waves: the persistent double-buffered form (opt-in, QE_PWR_PERSIST=1)
-    pl->persistent = !s2 && ks <= 4 && sh->OC >= 256 && groups == 1 && (env_get("QE_PWR_PERSIST") && atoi(env_get("QE_PWR_PERSIST")) == 1);   // opt-in: +13-20 % against one tile per workgroup (profiles/r03d_ab_persist.txt)
+    pl->persistent = !s2 && ks <= 4 && sh->OC >= 256 && groups == 1 && (env_get("QE_PWR_PERSIST") && atoi(env_get("QE_PWR_PERSIST")) == 1);   // opt-in: +10-23 % against one tile per workgroup, also with the tile requested two tiles ahead (profiles/r03d_ab_persist.txt, r03t_ab_persist2.txt)
     return true;
 }
 
 // 7x7 planes: 0 = not eligible, else images per tile
 static int pwr7_plan(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w, int *groups)
 {
-    int mode = 1;
+    int mode = 2;
     if (const char *e = env_get("QE_PWR")) mode = atoi(e);
     if (mode == 0 || (env_get("QE_PWR7") && atoi(env_get("QE_PWR7")) == 0)) return 0;
     if (sh->KH != 1 || sh->KW != 1 || sh->stride != 1 || sh->padding != 0 || sh->H * sh->W != 49) return 0;

@@ -7,7 +7,7 @@ rows = []
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-is_conv = lambda n: ("conv_mfma" in n or "conv_flatd" in n) and "prep" not in n
+is_conv = lambda n: any(k in n for k in ("conv_mfma", "conv_flatd", "conv_pwr", "conv_c3")) and "prep" not in n
 main = [i for i, r in enumerate(rows) if is_conv(r["Kernel_Name"])]
 assert len(main) % 53 == 0, len(main)
 first = main[-53]
