@@ -672,8 +672,9 @@ unsigned long long *g_mfma_dbg = nullptr;   // also read by qe_linear.hip (diagn
 int expand_codes_s8(const uint8_t *packed, int64_t n, int n_bits, int sign, uint8_t *out, hipStream_t s);   // qe_tpack.hip
 int flatd_variant(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w);                          // qe_conv_flatd.hip
 int launch_flatd(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh, float *out, hipStream_t s);
-bool pwr_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w);                          // qe_conv_pwr.hip
-int launch_pwr(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh, float *out, hipStream_t s);
+bool pwr_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w, const RequantHost *rq);  // qe_conv_pwr.hip
+int launch_pwr(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh, float *out, hipStream_t s,
+               const RequantHost *rq);
 bool c3_eligible(const MfmaArgs &a);                                                                          // qe_conv_c3.hip
 int launch_c3(const MfmaArgs &a, int64_t n_units, hipStream_t s);
 constexpr int QE_FLATD_DEFAULT = 4;   // 7x7 planes only: -17..-20 % there; the wide variants tie or lose to the register-staged kernels (profiles/r02b_ab_flatd.txt)
@@ -841,7 +842,7 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
 
     // 1x1 / stride 1 layers with 8-bit operands whose channel depth fits the LDS (IC = 64 | 128 | 256, OC >= 128): the
     // resident-tile kernel (qe_conv_pwr.hip).  QE_PWR=0 keeps the flat kernels below.
-    if (rq == nullptr && pwr_eligible(sh, x, w)) return mode == 1 ? QE_OK : launch_pwr(x, w, bias, sh, out, s);
+    if (pwr_eligible(sh, x, w, rq)) return mode == 1 ? QE_OK : launch_pwr(x, w, bias, sh, out, s, rq);
 
     // 1x1 / stride 1 layers with 8-bit operands and IC % 64 == 0: the LDS-DMA ring kernel (qe_conv_flatd.hip).
     // QE_FLATD=0 keeps the register-staged flat kernels; QE_FLATD=<bitmask> enables it per tile variant

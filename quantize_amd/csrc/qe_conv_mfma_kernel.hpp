@@ -66,7 +66,8 @@ struct RqConst {
     float sc, rcp, nsc, zr, qmin, qmax, offf, B, lo, hi;
     bool slow, chk;
 };
-__device__ __forceinline__ RqConst rq_setup(const MfmaArgs &a)
+template <class Args>                                      // MfmaArgs, PwrArgs: the same rq_* fields
+__device__ __forceinline__ RqConst rq_setup(const Args &a)
 {
     RqConst c;
     c.sc = a.rq_scale[0];
@@ -102,7 +103,33 @@ __device__ __forceinline__ float rq_value(const RqConst &c, float v, bool &bad)
     }
     return r + c.offf;
 }
-__device__ __forceinline__ void rq_report(const MfmaArgs &a, bool bad)
+// Two values per instruction where the ISA has packed fp32 (v_pk_mul_f32, v_pk_fma_f32, v_pk_add_f32: 7.5 instead of 13 VALU
+// instructions per output element; the fused epilogue is VALU-bound: 2.8 G elements per batch-256 ResNet-50 step).  Valid
+// when rq_fast_ok(c) and the caller has bounded its own constants so that y is finite and |y| <= 2^52 (rq_bounded): then
+// no NaN and no overflow can occur anywhere in the sequence, the +-B clamp of rq_value is the identity wherever it matters
+// (beyond B the code is the clamp bound either way) and no range flag can be raised -- the same codes as rq_value.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bool rq_fast_ok(const RqConst &c) { return !c.slow && !c.chk; }
+// |alpha| <= 2^10, |cst| <= 2^40, |bias| <= 2^50, |zw'| <= 2^20: y = fma(alpha, acc + cst - zw' S_x, bias) stays below 2^52
+__device__ __forceinline__ bool rq_bounded(float alpha, float cst, float bias, float zwp)
+{
+    return fabsf(alpha) <= 0x1p10f && fabsf(cst) <= 0x1p40f && fabsf(bias) <= 0x1p50f && fabsf(zwp) <= 0x1p20f;
+}
+__device__ __forceinline__ v2f rq_fast2(const RqConst &c, v2f y)
+{
+#pragma clang fp contract(off)
+    const v2f rcp = {c.rcp, c.rcp}, nsc = {c.nsc, c.nsc}, zr = {c.zr, c.zr}, off = {c.offf, c.offf};
+    const v2f q0 = y * rcp;
+    const v2f e = __builtin_elementwise_fma(nsc, q0, y);
+    const v2f q = __builtin_elementwise_fma(e, rcp, q0);
+    const v2f d = q - zr;
+    v2f r;
+    r.x = __builtin_amdgcn_fmed3f(rintf(d.x), c.qmin, c.qmax);
+    r.y = __builtin_amdgcn_fmed3f(rintf(d.y), c.qmin, c.qmax);
+    return r + off;
+}
+template <class Args>
+__device__ __forceinline__ void rq_report(const Args &a, bool bad)
 {
     if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0 && a.rq_status != nullptr) atomicOr(a.rq_status, 1);
 }
@@ -1735,23 +1762,47 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
         // patch in LDS (behind the staging image and the channel sums: a.ptab_off), then every thread stores 16-byte
         // pieces of rows: NTP contiguous bytes per output channel instead of 4 x NTP.
         uint8_t *bp = smem + a.ptab_off;                                       // [MT][NTP]
-        const RqConst rqc = rq_setup(a);
+        RqConst rqc = rq_setup(a);
+        rqc.slow = __builtin_amdgcn_readfirstlane(rqc.slow);                   // the same in every lane: a branch, not a select
+        rqc.chk = __builtin_amdgcn_readfirstlane(rqc.chk);
         bool bad = false;
+        // wave-uniform: packed pairs (rq_fast2) when no check can fire, else element by element
+        const bool fast = rq_fast_ok(rqc) && __builtin_amdgcn_ballot_w64(!rq_bounded(alpha, cst, bia, zwp)) == 0ull;
+        auto body = [&](auto fast_tag, auto sx_tag) __attribute__((always_inline)) {
+            constexpr bool FAST = decltype(fast_tag)::value, SXE = decltype(sx_tag)::value;
 #pragma unroll
-        for (int t = 0; t < NIW; ++t) {
-            const int q0 = (wn + t * WN) * 32;
+            for (int t = 0; t < NIW; ++t) {
+                const int q0 = (wn + t * WN) * 32;
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                uint32_t pk = 0;
+                for (int gq = 0; gq < 4; ++gq) {
+                    uint32_t pk = 0;
+                    if constexpr (FAST) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float f = (float)acc[t][4 * gq + j] + cst;
-                    if (need_sx) f = fmaf(-zwp, (float)sxp[q0 + 8 * gq + 4 * h + j], f);
-                    pk = __builtin_amdgcn_cvt_pk_u8_f32(rq_value(rqc, fmaf(alpha, f, bia), bad), j, pk);
+                        for (int j = 0; j < 4; j += 2) {
+                            v2f f = {(float)acc[t][4 * gq + j], (float)acc[t][4 * gq + j + 1]};
+                            f = f + v2f{cst, cst};
+                            if constexpr (SXE) {
+                                const v2f sx2 = {(float)sxp[q0 + 8 * gq + 4 * h + j], (float)sxp[q0 + 8 * gq + 4 * h + j + 1]};
+                                f = __builtin_elementwise_fma(v2f{-zwp, -zwp}, sx2, f);
+                            }
+                            const v2f r = rq_fast2(rqc, __builtin_elementwise_fma(v2f{alpha, alpha}, f, v2f{bia, bia}));
+                            pk = __builtin_amdgcn_cvt_pk_u8_f32(r.x, j, pk);
+                            pk = __builtin_amdgcn_cvt_pk_u8_f32(r.y, j + 1, pk);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float f = (float)acc[t][4 * gq + j] + cst;
+                            if (need_sx) f = fmaf(-zwp, (float)sxp[q0 + 8 * gq + 4 * h + j], f);
+                            pk = __builtin_amdgcn_cvt_pk_u8_f32(rq_value(rqc, fmaf(alpha, f, bia), bad), j, pk);
+                        }
+                    }
+                    *reinterpret_cast<uint32_t *>(bp + (wm * 32 + col) * NTP + q0 + 8 * gq + 4 * h) = pk;
                 }
-                *reinterpret_cast<uint32_t *>(bp + (wm * 32 + col) * NTP + q0 + 8 * gq + 4 * h) = pk;
             }
-        }
+        };
+        if (fast) { if (need_sx) body(std::true_type{}, std::true_type{}); else body(std::true_type{}, std::false_type{}); }
+        else body(std::false_type{}, std::false_type{});
         // lanes of channel rows >= OC and pixels >= NT computed on padding: their codes are never stored, their range flags dropped
         if (oc >= a.OC) bad = false;
         __syncthreads();

@@ -44,6 +44,12 @@ struct PwrArgs {
     int strips_per_group;      // 32-channel strips of one group
     unsigned long long *dbg;   // diagnostic builds (-DQE_STAMP) only: per-wave phase cycle sums
     int W_in, PIN, OW;         // stride-2 form: input row length, input plane size, output row length (P = output plane)
+    // fused re-quantisation (RQ instances): the 8-bit code of the consumer's quantiser instead of fp32, fields as in MfmaArgs
+    uint8_t *rq_out;
+    const float *rq_scale, *rq_zero;
+    float rq_qmin, rq_qmax, rq_lo, rq_hi;
+    unsigned rq_offset;
+    int32_t *rq_status;
 };
 
 // NT column tiles of 32 pixel slots (odd), of which the first TW pixels are real: every tile of a launch has the same
@@ -60,6 +66,8 @@ template <int NT, int WAVES, int KS, int TW> struct PwrGeom {
     static constexpr int PATCH = 8 * TW * 4;                 // per wave: 8 channel rows x the tile width, fp32
     static constexpr int PPR = TW / 4;                       // 16-byte pieces per patch row
     static constexpr int NRB = (8 * PPR + 63) / 64;          // read-back / store rounds per register quad
+    static constexpr int PPRB = (TW + 15) / 16;              // RQ: 16-byte pieces per row of codes (the last one shifted back to end at the row's end)
+    static constexpr int NRQ = (32 * PPRB + 63) / 64;        // RQ: store rounds per STRIP (32 rows of TW bytes through the same patch space)
     static constexpr int LDS = XBYTES + TAB + WAVES * PATCH;
 };
 
@@ -70,7 +78,11 @@ template <int NT, int WAVES, int KS, int TW> struct PwrGeom {
 // S2: 1x1 / stride 2 / pad 0 (the downsample branch of a stage's first block): the tile is TW / OW output rows; its
 // pixels are the even columns of the even input rows, fetched ONCE per tile as 8-byte pieces of those rows (registers,
 // v_perm keeps the even bytes, ds_write_b32) instead of once per 128 output channels by the flat kernel's strided staging.
-template <int NT, int WAVES, int KS, int TW, bool S2 = false>
+// RQ: fused re-quantisation (qe_quantconv2d_requant_prepared).  The operand roles are swapped (A = activations, B = weights:
+// the transposed accumulator), so a lane owns ONE output channel and 4 consecutive pixels per register quad: its channel
+// constants are its own registers (no table), four codes pack into a dword (v_cvt_pk_u8_f32) and the strip's 32 rows x TW
+// bytes go through the wave's patch once: NRQ = 7 store instructions per strip instead of 28.
+template <int NT, int WAVES, int KS, int TW, bool S2 = false, bool RQ = false>
 __global__ __launch_bounds__(64 * WAVES, 2) void conv_pwr_kernel(const PwrArgs a)
 {
     using G = PwrGeom<NT, WAVES, KS, TW>;
@@ -218,6 +230,35 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_pwr_kernel(const PwrArgs a
         rb_off[k] = f < 8 * G::PPR ? (uint32_t)row * (uint32_t)P + 4u * (uint32_t)pc : 0u;
     }
 
+    // RQ: piece f = 64 k + lane of the strip's 32 x TW bytes of codes.  Tile = whole plane: the 32 rows are ONE contiguous
+    // run of the output, copied flat as aligned pieces; else row f / PPRB, piece f % PPRB, the last piece of a row shifted
+    // back to end at the row's end (dword-aligned 16-byte stores; the bytes two pieces share hold the same codes).
+    uint32_t rq_lds[RQ ? G::NRQ : 1], rq_glb[RQ ? G::NRQ : 1];
+    bool rq_live[RQ ? G::NRQ : 1];
+    if constexpr (RQ) {
+#pragma unroll
+        for (int k = 0; k < G::NRQ; ++k) {
+            const int f = 64 * k + lane;
+            if (P == TW) {
+                rq_live[k] = 16 * f < 32 * TW;
+                rq_lds[k] = rq_glb[k] = rq_live[k] ? 16u * (uint32_t)f : 0u;
+            } else {
+                const int row = f / G::PPRB, pc = f - row * G::PPRB;
+                const int boff = 16 * pc < TW - 16 ? 16 * pc : TW - 16;
+                rq_live[k] = f < 32 * G::PPRB;
+                rq_lds[k] = rq_live[k] ? (uint32_t)(row * TW + boff) : 0u;
+                rq_glb[k] = rq_live[k] ? (uint32_t)row * (uint32_t)P + (uint32_t)boff : 0u;
+            }
+        }
+    }
+    RqConst rqc;
+    bool bad = false, rq_fast_u = false;
+    if constexpr (RQ) {
+        rqc = rq_setup(a);
+        rqc.slow = __builtin_amdgcn_readfirstlane(rqc.slow);      // the same in every lane: say so (or every use becomes a select)
+        rqc.chk = __builtin_amdgcn_readfirstlane(rqc.chk);
+        rq_fast_u = rq_fast_ok(rqc);
+    }
     const float zxp = a.x_zero[0] - (a.x_sign ? 0.0f : 128.0f);
     const float sx = a.x_scale[0];
     const float zw_shift = a.w_sign ? 0.0f : 128.0f;
@@ -277,7 +318,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_pwr_kernel(const PwrArgs a
 #pragma unroll
                     for (int j = 0; j < 4; ++j) sxacc[t] = __builtin_amdgcn_sdot4(xf[j], 0x01010101, sxacc[t], false);
                 }
-                acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wk, xf, acc[t], 0, 0, 0);
+                if constexpr (RQ) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xf, wk, acc[t], 0, 0, 0);
+                else acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wk, xf, acc[t], 0, 0, 0);
             }
         }
         if constexpr (SX) {
@@ -289,10 +331,70 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_pwr_kernel(const PwrArgs a
     // epilogue of the strip whose sums sit in acc / swacc; (e_sw, e_zw, e_bi) = its lane's channel constants.
     // next >= 0: the next strip's weights are requested in front of this strip's N_YOUNGER stores (vmcnt is a 6-bit in-order
     // counter: the wait for the weights names the stores issued behind them).
-    constexpr int N_YOUNGER = 4 * NRB;
+    constexpr int N_YOUNGER = RQ ? G::NRQ : 4 * NRB;
     static_assert(N_YOUNGER <= 63, "vmcnt is a 6-bit counter");
     auto epilogue = [&](int strip, float e_sw, float e_zw, float e_bi, bool need_sx) __attribute__((always_inline)) {
         const int oc0 = strip * 32;
+        if constexpr (RQ) {
+            // lane col owns channel oc0 + col (its own constants); register 4 gq + j of column tile t = pixel 32 t + 8 gq + 4 h + j.
+            // The fp32 value is computed exactly as in the fp32 form below, then quantised as quantize_pack would.
+            const float zwp = e_zw - zw_shift;
+            const int sw_sum = swacc + __shfl_xor(swacc, 32);
+            const float cst = fmaf((float)G::IC * zxp, zwp, -zxp * (float)sw_sum);
+            const float alpha = sx * e_sw;
+            uint8_t *bp = reinterpret_cast<uint8_t *>(patch);                  // [32][TW] codes
+            // wave-uniform choice (a real branch: left to itself hipcc evaluates both forms for every element and selects):
+            // packed pairs when nothing can overflow or trip the range flag, else element by element with every check
+            const bool fast = rq_fast_u && __builtin_amdgcn_ballot_w64(!rq_bounded(alpha, cst, e_bi, zwp)) == 0ull;
+            auto body = [&](auto fast_tag, auto sx_tag) __attribute__((always_inline)) {
+                constexpr bool FAST = decltype(fast_tag)::value, SXE = decltype(sx_tag)::value;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int px = 32 * t + 8 * gq + 4 * h;                // first of the 4 pixels; TW % 4 == 0: all four are real or none
+                        const bool real = 32 * t + 32 <= TW || px < TW;        // first term compile-time
+                        uint32_t pk = 0;
+                        if constexpr (FAST) {
+#pragma unroll
+                            for (int j = 0; j < 4; j += 2) {
+                                v2f f = {(float)acc[t][4 * gq + j], (float)acc[t][4 * gq + j + 1]};
+                                f = f + v2f{cst, cst};
+                                if constexpr (SXE) {
+                                    const v2f sxp = {__shfl(sxv[t], 8 * gq + 4 * h + j), __shfl(sxv[t], 8 * gq + 4 * h + j + 1)};
+                                    f = __builtin_elementwise_fma(v2f{-zwp, -zwp}, sxp, f);
+                                }
+                                const v2f r = rq_fast2(rqc, __builtin_elementwise_fma(v2f{alpha, alpha}, f, v2f{e_bi, e_bi}));
+                                pk = __builtin_amdgcn_cvt_pk_u8_f32(r.x, j, pk);
+                                pk = __builtin_amdgcn_cvt_pk_u8_f32(r.y, j + 1, pk);
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                float f = (float)acc[t][4 * gq + j] + cst;
+                                if (need_sx) f = fmaf(-zwp, __shfl(sxv[t], 8 * gq + 4 * h + j), f);
+                                bool b = false;
+                                const float r = rq_value(rqc, fmaf(alpha, f, e_bi), b);
+                                bad |= b && real;                              // padding slots hold whatever followed the tile
+                                pk = __builtin_amdgcn_cvt_pk_u8_f32(r, j, pk);
+                            }
+                        }
+                        if (real) *reinterpret_cast<uint32_t *>(bp + col * TW + px) = pk;
+                    }
+                }
+            };
+            if (fast) { if (need_sx) body(std::true_type{}, std::true_type{}); else body(std::true_type{}, std::false_type{}); }
+            else body(std::false_type{}, std::false_type{});
+            uint8_t *out_q = a.rq_out + ((int64_t)n0 * a.OC + oc0) * P + p0;   // wave-uniform
+#pragma unroll
+            for (int k = 0; k < G::NRQ; ++k) {
+                uint4 d4;
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(bp + rq_lds[k]);   // dword aligned
+                d4.x = src[0]; d4.y = src[1]; d4.z = src[2]; d4.w = src[3];
+                if (rq_live[k]) __builtin_memcpy(out_q + rq_glb[k], &d4, 16);
+            }
+            return;
+        }
         {
             // lane col owns channel oc0 + col; the accumulator rows read the constants back from LDS
             const float zwp = e_zw - zw_shift;
@@ -367,6 +469,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_pwr_kernel(const PwrArgs a
         QE_ST(3);
     }
     epilogue(strip0 + (n_my - 1) * WAVES, c_sw, c_zw, c_bi, sx_cur);
+    if constexpr (RQ) rq_report(a, bad);
 #ifdef QE_STAMP
     QE_ST(4);
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): stores acknowledged
@@ -959,10 +1062,17 @@ static int pwr7_plan(const qe_conv_shape *sh, const qe_qparam *x, const qe_qpara
     return gi;
 }
 
-bool pwr_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w)
+// rq != nullptr: the fused re-quantising form (8-bit codes, one scale: what the kernels' epilogue covers); the 7x7 and the
+// persistent kernels have none
+bool pwr_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w, const RequantHost *rq)
 {
     PwrPlan pl;
     int g;
+    if (rq != nullptr) {
+        if (rq->n_bits != 8 || rq->n_param != 1 || rq->out == nullptr || (reinterpret_cast<uintptr_t>(rq->out) & 15) != 0) return false;
+        if (env_get("QE_PWR_RQ") && atoi(env_get("QE_PWR_RQ")) == 0) return false;
+        return pwr_plan(sh, x, w, &pl) && !pl.persistent;
+    }
     return pwr_plan(sh, x, w, &pl) || pwr7_plan(sh, x, w, &g) != 0;
 }
 
@@ -1000,12 +1110,22 @@ static int launch_pwr7(const qe_qparam *x, const qe_qparam *w, const float *bias
     return QE_OK;
 }
 
-int launch_pwr(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh, float *out, hipStream_t s)
+int launch_pwr(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh, float *out, hipStream_t s,
+               const RequantHost *rq)
 {
-    if (sh->H * sh->W == 49) return launch_pwr7(x, w, bias, sh, out, s);
+    if (sh->H * sh->W == 49) return rq != nullptr ? QE_ERR_UNSUPPORTED : launch_pwr7(x, w, bias, sh, out, s);
     PwrPlan pl;
     if (!pwr_plan(sh, x, w, &pl)) return QE_ERR_UNSUPPORTED;
     PwrArgs a;
+    a.rq_out = nullptr; a.rq_scale = nullptr; a.rq_zero = nullptr; a.rq_status = nullptr;
+    a.rq_qmin = a.rq_qmax = a.rq_lo = a.rq_hi = 0.0f; a.rq_offset = 0;
+    if (rq != nullptr) {
+        if (!pwr_eligible(sh, x, w, rq)) return QE_ERR_UNSUPPORTED;
+        a.rq_out = rq->out; a.rq_scale = rq->scale; a.rq_zero = rq->zero;
+        a.rq_qmin = rq->qmin; a.rq_qmax = rq->qmax; a.rq_status = rq->status;
+        a.rq_offset = rq->sign ? 128u : 0u;                       // tpack.cu:108-111
+        a.rq_lo = rq->sign ? -128.0f : 0.0f; a.rq_hi = rq->sign ? 127.0f : 255.0f;
+    }
     a.x = static_cast<const uint8_t *>(x->data); a.w = static_cast<const uint8_t *>(w->data);
     a.x_scale = x->scale; a.x_zero = x->zero; a.w_scale = w->scale; a.w_zero = w->zero; a.bias = bias;
     a.x_sign = x->sign; a.w_sign = w->sign; a.w_per_tensor = (w->n_param == 1);
@@ -1027,7 +1147,7 @@ int launch_pwr(const qe_qparam *x, const qe_qparam *w, const float *bias, const 
     const int64_t runs = ((int64_t)a.n_pix_tiles + a.chunk - 1) / a.chunk;
     const int64_t blocks = (runs + 7) / 8 * a.chunk * 8 * a.n_groups;
     if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
-    if (pl.persistent) {
+    if (pl.persistent && rq == nullptr) {
         int grid = kNumCU;
         if (const char *e = env_get("QE_PWR_GRID")) { const int v = atoi(e); if (v >= 1) grid = v; }
         if (grid > a.n_pix_tiles) grid = a.n_pix_tiles;
@@ -1045,14 +1165,15 @@ int launch_pwr(const qe_qparam *x, const qe_qparam *w, const float *bias, const 
         QE_LAUNCH_CHECK();
         return QE_OK;
     }
-#define QE_PWR_LAUNCH1(WV, KSV, TWV, S2V)                                                                                  \
+#define QE_PWR_LAUNCH2(WV, KSV, TWV, S2V, RQV)                                                                             \
     do {                                                                                                                    \
-        static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pwr_kernel<7, WV, KSV, TWV, S2V>), \
+        static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pwr_kernel<7, WV, KSV, TWV, S2V, RQV>), \
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, PwrGeom<7, WV, KSV, TWV>::LDS) == hipSuccess; \
         (void)ok_;                                                                                                          \
         constexpr size_t lds_ = PwrGeom<7, WV, KSV, TWV>::LDS;                                                              \
-        hipLaunchKernelGGL((conv_pwr_kernel<7, WV, KSV, TWV, S2V>), dim3((unsigned)blocks), dim3(64 * WV), lds_, s, a);     \
+        hipLaunchKernelGGL((conv_pwr_kernel<7, WV, KSV, TWV, S2V, RQV>), dim3((unsigned)blocks), dim3(64 * WV), lds_, s, a); \
     } while (0)
+#define QE_PWR_LAUNCH1(WV, KSV, TWV, S2V) do { if (rq != nullptr) QE_PWR_LAUNCH2(WV, KSV, TWV, S2V, true); else QE_PWR_LAUNCH2(WV, KSV, TWV, S2V, false); } while (0)
 #define QE_PWR_LAUNCH(WV, KSV, TWV) do { if (pl.s2) QE_PWR_LAUNCH1(WV, KSV, TWV, true); else QE_PWR_LAUNCH1(WV, KSV, TWV, false); } while (0)
     if (pl.tw == 224) {
         if (pl.ks == 2) QE_PWR_LAUNCH(4, 2, 224); else if (pl.ks == 4) QE_PWR_LAUNCH(4, 4, 224); else QE_PWR_LAUNCH(8, 8, 224);
@@ -1060,6 +1181,7 @@ int launch_pwr(const qe_qparam *x, const qe_qparam *w, const float *bias, const 
         if (pl.ks == 2) QE_PWR_LAUNCH(4, 2, 196); else if (pl.ks == 4) QE_PWR_LAUNCH(4, 4, 196); else QE_PWR_LAUNCH(8, 8, 196);
     }
 #undef QE_PWR_LAUNCH1
+#undef QE_PWR_LAUNCH2
 #undef QE_PWR_LAUNCH
     QE_LAUNCH_CHECK();
     return QE_OK;

@@ -29,6 +29,13 @@ SHAPES = [
     (5, 512, 7, 7, 512, 3, 1, 1),       # warp-specialised
     (2, 3, 64, 64, 64, 7, 2, 3),        # stem
     (2, 33, 9, 9, 31, 5, 1, 2),         # generic taps, tiny
+    # the resident-tile 1x1 kernel's own re-quantising epilogue (qe_conv_pwr.hip, RQ instances)
+    (2, 128, 28, 28, 512, 1, 1, 0),     # 196-byte row pieces of 784-byte planes (last 16-byte piece of a row shifted back)
+    (1, 256, 28, 28, 512, 1, 1, 0),     # 8 waves
+    (3, 256, 56, 56, 512, 1, 2, 0),     # its stride-2 form
+    (2, 64, 28, 64, 256, 1, 2, 0),      # stride 2, 224-byte row pieces
+    (40, 64, 14, 14, 192, 1, 1, 0),     # whole-plane tiles: a strip's 32 planes are one 6272-byte run; more tiles than XCDs
+    (3, 128, 14, 14, 160, 1, 1, 0),     # 5 strips on 4 waves
 ]
 
 
@@ -43,8 +50,21 @@ def _case_tensors(case):
     return sh, xq, wq, bias
 
 
-@pytest.mark.parametrize("sign", [True, False])
-def test_requant_equals_conv_then_quantize_pack(engine, sign):
+@pytest.fixture
+def fresh_env():
+    """The library reads QE_* once per process: re-read after the test's monkeypatch is undone."""
+    yield
+    import os
+    os.environ.pop("QE_PWR_RQ", None)
+    capi.reload_env()
+
+
+@pytest.mark.parametrize("sign,pwr_rq", [(True, "1"), (False, "1"), (True, "0")])
+def test_requant_equals_conv_then_quantize_pack(engine, sign, pwr_rq, monkeypatch, fresh_env):
+    """pwr_rq = 0: the resident-tile kernel's re-quantising instances off -- the flat kernels' fused epilogue against the
+    fp32 output of the resident-tile kernel (two kernels, one arithmetic)."""
+    monkeypatch.setenv("QE_PWR_RQ", pwr_rq)
+    capi.reload_env()
     rng = np.random.RandomState(77 + sign)
     for shp in SHAPES:
         for zeros in (False, True):
