@@ -281,13 +281,35 @@ __device__ __forceinline__ void mfma_epilogue_impl(const MfmaArgs &a, v16i (&acc
         // symmetric operands: out = bias + alpha * S_aw.  Store address = wave-uniform row base
         // (scalar) + one per-lane 32-bit offset: lanes 0-31 are 32 consecutive pixels of row dr,
         // lanes 32-63 of row dr + 4 -> two full 128-byte lines per store instruction.
+        // RQ: two registers (channel rows dr, dr + 1) per packed instruction when no check can fire (rq_fast2)
+        bool fast = false;
+        if constexpr (RQ) {
+            rqc.slow = __builtin_amdgcn_readfirstlane(rqc.slow);
+            rqc.chk = __builtin_amdgcn_readfirstlane(rqc.chk);
+            bool ok = true;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ok = ok && rq_bounded(al[r], 0.0f, bi[r], 0.0f);
+            fast = rq_fast_ok(rqc) && __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+        }
 #pragma unroll
         for (int t = 0; t < NIW; ++t) {
             const int q0 = (wn + t * WN) * 32;
             if (full_oc && q0 + 32 <= g.NT) {
+                if (RQ && fast) {
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const int dr = (r & 3) + 8 * (r >> 2);
+                        const v2f y = __builtin_elementwise_fma(v2f{al[r], al[r + 1]}, v2f{(float)acc[t][r], (float)acc[t][r + 1]},
+                                                                v2f{bi[r], bi[r + 1]});
+                        const v2f c2 = rq_fast2(rqc, y);
+                        (out_q + (int64_t)dr * OHW)[voff[t]] = (uint8_t)(unsigned)c2.x;
+                        (out_q + (int64_t)(dr + 1) * OHW)[voff[t]] = (uint8_t)(unsigned)c2.y;
+                    }
+                } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     emit(r, (r & 3) + 8 * (r >> 2), t, fmaf(al[r], (float)acc[t][r], bi[r]));
+                }
                 }
             } else {
 #pragma unroll

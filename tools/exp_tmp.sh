@@ -1,9 +1,5 @@
 set -o pipefail
-timeout -k 10 600 python -m pytest tests/test_requant_gpu.py tests/test_packed_modules_gpu.py -x -q > gpurun_out/r03u_rq_test.txt 2>&1; rc=$?; tail -5 gpurun_out/r03u_rq_test.txt; [ $rc -eq 0 ] || exit 1
-AB_EXTRA="--cold --fused-requant --layers 3,5,13,14,15,26,28,30" bash tools/ab_env.sh QE_PWR_RQ 0 1 > gpurun_out/r03u_ab_pwr_rq_layers.txt 2>&1
-grep -E "^ *[0-9]+ layer" gpurun_out/ab_QE_PWR_RQ_0.err gpurun_out/ab_QE_PWR_RQ_1.err
-for v in 0 1 0 1; do
-  QE_PWR_RQ=$v timeout -k 10 200 python bench.py --steps 100 --warmup 5 --no-cpu-baseline --fused-requant > gpurun_out/r03u_fused_$v.json 2> gpurun_out/r03u_fused_$v.err || exit 1
-  python -c "
-import json;j=json.load(open('gpurun_out/r03u_fused_$v.json'));print('QE_PWR_RQ=$v', j['value'], j['ms_per_step'], j['roofline']['conv_stack_ms'])"
-done | tee gpurun_out/r03u_ab_pwr_rq.txt
+timeout -k 10 600 python -m pytest tests/test_requant_gpu.py -x -q > gpurun_out/r03u_rq_test.txt 2>&1; rc=$?; tail -5 gpurun_out/r03u_rq_test.txt; [ $rc -eq 0 ] || exit 1
+timeout -k 10 300 python bench.py --steps 5 --warmup 2 --per-layer --cold --no-cpu-baseline --fused-requant --layers 0,2,6,12,16,19,25,29,32,44,48,51,52 > gpurun_out/r03u_fused_pl.json 2> gpurun_out/r03u_fused_pl.err; grep -E "^ *[0-9]+ (layer|conv)|sum of" gpurun_out/r03u_fused_pl.err
+timeout -k 10 200 python bench.py --steps 100 --warmup 5 --no-cpu-baseline --fused-requant > gpurun_out/r03u_fused.json 2> gpurun_out/r03u_fused.err; python -c "
+import json;j=json.load(open('gpurun_out/r03u_fused.json'));print(j['value'], j['ms_per_step'], j['roofline']['conv_stack_ms'])"
