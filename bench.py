@@ -67,6 +67,11 @@ def parse_args():
                          "once per layer at set-up (qe_conv_prepare + qe_quantconv2d_prepared: a packed layer's weights do not "
                          "change between forward passes)")
     ap.add_argument("--layers", type=str, default="", help="comma list of layer indices (debug)")
+    ap.add_argument("--layer-streams", type=int, default=1,
+                    help="DIAGNOSTIC: issue layer i on stream i %% S (the 53 problems are independent in this bench; a real network's "
+                         "layers are not) -- bounds what co-scheduling kernels of different phases could buy")
+    ap.add_argument("--mb-stagger", type=int, default=0,
+                    help="with --microbatches M: micro-batch m starts m*K layers behind micro-batch 0")
     ap.add_argument("--microbatches", type=int, default=1,
                     help="split the batch into M micro-batches, each walking the 53 layers on its own HIP stream (kernels of "
                          "different micro-batches overlap; not the headline, whose roofline is per launch)")
@@ -332,14 +337,42 @@ def main():
         mb_ev = [torch.cuda.Event() for _ in range(M)]
         fork_ev = torch.cuda.Event()
 
+    LS = args.layer_streams
+    if LS > 1:
+        assert M == 1 and not args.graph
+        ls_streams = [torch.cuda.Stream(device=dev) for _ in range(LS)]
+        ls_sp = [ctypes.c_void_p(st.cuda_stream) for st in ls_streams]
+        ls_ev = [torch.cuda.Event() for _ in range(LS)]
+        ls_fork = torch.cuda.Event()
+    if M > 1 and args.mb_stagger:
+        stag_ev = [torch.cuda.Event() for _ in range(M)]
+
     def step():
+        if LS > 1:
+            ls_fork.record(stream)
+            for s_ in ls_streams:
+                s_.wait_event(ls_fork)
+            for i, L in enumerate(layers):
+                L.run(ls_sp[i % LS])
+            for m in range(LS):
+                ls_ev[m].record(ls_streams[m])
+                stream.wait_event(ls_ev[m])
+            return
         if M > 1:
             fork_ev.record(stream)
             for m in range(M):
                 mb_streams[m].wait_event(fork_ev)
-            for i in range(len(specs)):            # interleaved issue order; each stream stays in order
+            K = args.mb_stagger
+            for i in range(len(specs) + K * (M - 1)):   # interleaved issue order; each stream stays in order
                 for m in range(M):
-                    mb_layers[m][i].run(mb_sp[m])
+                    li = i - m * K
+                    if li < 0 or li >= len(specs):
+                        continue
+                    if K and m > 0 and li == 0:         # micro-batch m starts when micro-batch m-1 has finished K layers
+                        mb_streams[m].wait_event(stag_ev[m - 1])
+                    mb_layers[m][li].run(mb_sp[m])
+                    if K and li == K - 1 and m + 1 < M:
+                        stag_ev[m].record(mb_streams[m])
             for m in range(M):
                 mb_ev[m].record(mb_streams[m])
                 stream.wait_event(mb_ev[m])
@@ -379,7 +412,9 @@ def main():
                 graph = None
     run_step = graph.replay if graph is not None else step
     if M > 1:
-        launch_mode = launch_mode_mb
+        launch_mode = launch_mode_mb + (", staggered by %d layers" % args.mb_stagger if args.mb_stagger else "")
+    if LS > 1:
+        launch_mode = "DIAGNOSTIC: layer i on stream i %% %d (independent problems co-scheduled)" % LS
 
     with torch.cuda.stream(stream):
         for _ in range(args.warmup):

@@ -898,6 +898,16 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
 
     a.n_pix_tiles = ((sh->N + p.GI - 1) / p.GI) * a.tiles_h;
     a.n_oc_tiles = p.OCP / p.MT;
+    // flat 1x1, deep reductions into >= 256 output channels (1024 -> 256 @14x14, 512 -> 256 @28x28, ...): 8-wave workgroups
+    // that own 256 output channels of a pixel tile, so the tile's activations cross the CU's memory path OC / 256 times
+    // instead of OC / 128 (these layers are bound by the bytes through that path).  Weights straight
+    // from the packed tensor only (no prepared-table layout depends on the channel tile).  Opt-in (QE_FLAT8=1; 3: IC = 1024
+    // only; 2: without the deep prefetch): cold per-layer A/B -7 % on 1024 -> 256 @14x14, but the step as a whole does not
+    // gain (profiles/r03w_ab_flat8*.txt).
+    const bool wide8 = p.flat && !p.s2 && !p.x4 && !p.flatg && p.cfg == 0 && p.wraw && rq == nullptr && p.NS == 4 &&
+                       (p.niw == 7 || p.niw == 5) && sh->IC >= 512 && sh->OC % 256 == 0 &&
+                       (env_get("QE_FLAT8") ? atoi(env_get("QE_FLAT8")) != 0 && (atoi(env_get("QE_FLAT8")) != 3 || sh->IC == 1024) : false);
+    if (wide8) a.n_oc_tiles = sh->OC / 256;
     int64_t n_units = a.n_pix_tiles;             // what the XCD-aware block map distributes
     if (p.flatg) {
         a.tiles_h = 1;                           // one tile = GI whole images
@@ -968,6 +978,14 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     }
     if (p.flat && p.x4) {
         launch_mfma_flat_x4(a, p.niw, p.NS, (unsigned)blocks, lds_f, s);
+        QE_LAUNCH_CHECK();
+        return QE_OK;
+    }
+    if (p.flat && wide8) {
+        const size_t lds8 = std::max((size_t)(32 * p.NS) * (32 * (p.ni | 1)), (size_t)8 * 32 * 36 * 4) + (size_t)(32 * p.ni) * 4;
+        // QE_FLAT8=2: without the deep-prefetch form (one register set of activation pieces, dynamic stage loop)
+        const bool deep = (sh->IC == 512 || sh->IC == 1024) && !(env_get("QE_FLAT8") && atoi(env_get("QE_FLAT8")) == 2);
+        launch_mfma_flat(a, deep ? 4 : 3, p.niw, p.NS, true, false, (unsigned)blocks, lds8, s);
         QE_LAUNCH_CHECK();
         return QE_OK;
     }

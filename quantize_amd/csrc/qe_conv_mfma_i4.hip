@@ -31,6 +31,14 @@ void launch_mfma_flat(const MfmaArgs &a, int cfg, int niw, int ns, bool wraw, bo
             if (niw == 4) QE_FLAT_NS(4, 1, 4); else if (niw == 5) QE_FLAT_NS(4, 1, 5); else QE_FLAT_NS(4, 1, 7);
             break;
         case 1: QE_FLAT_NS(2, 2, 4); break;
+        case 3:   // 8 waves x 32 output channels, 128-channel stages, packed weights (launch_conv_mfma: wide8)
+        case 4:   // ... K loop unrolled over IC / 128 = 4 | 8 stages, activations two stages ahead
+#define QE_FLAT8(NIW, NST) hipLaunchKernelGGL((conv_mfma_flat_kernel<8, 1, NIW, 4, true, false, false, NST>), dim3(blocks), dim3(512), lds, s, a)
+            if (cfg == 4 && a.IC == 512) { if (niw == 5) QE_FLAT8(5, 4); else QE_FLAT8(7, 4); }
+            else if (cfg == 4 && a.IC == 1024) { if (niw == 5) QE_FLAT8(5, 8); else QE_FLAT8(7, 8); }
+            else { if (niw == 5) QE_FLAT8(5, 0); else QE_FLAT8(7, 0); }
+#undef QE_FLAT8
+            break;
         default: QE_FLAT_NS(1, 4, 2); break;
     }
 }

@@ -1519,9 +1519,14 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 
 // X4: 4-bit activations consumed straight from the packed stream (a piece = 16 pixels = 8 bytes, nibbles spread to bytes
 // in the staging registers) instead of being expanded to 8-bit codes by a pass of their own first.
-template <int WM, int WN, int NIW, int NS, bool WRAW, bool S2, bool X4 = false>
-__global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const MfmaArgs a)
+// NSTAGES > 0 (8-wave instances): the K loop fully unrolled over exactly NSTAGES stages with the activations requested TWO
+// stages ahead (two register sets of PPT pieces: 4 each with 512 threads) and the weights one stage ahead, so a request is in
+// flight at every moment of a stage -- with one set the time from a stage's arrival to the next request (LDS writes, barrier)
+// plus a full memory round trip is serial in every stage.
+template <int WM, int WN, int NIW, int NS, bool WRAW, bool S2, bool X4 = false, int NSTAGES = 0>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4) ? 1 : 2) void conv_mfma_flat_kernel(const MfmaArgs a)
 {
+    constexpr int THR = 64 * WM * WN;           // 4 waves; 8 (WM = 8: 256 output channels per workgroup, one workgroup per CU)
     static_assert(!(X4 && S2), "the stride-2 staging takes 8-bit codes");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
@@ -1534,7 +1539,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
     // S2 (1x1, stride 2, no padding): the GEMM runs over the flat OUTPUT pixels; a piece is 16 input bytes of
     // an even input row, of which the 8 even columns are kept.  Pieces per thread then depend on the row
     // geometry (rows x segments of the tile): 8 slots cover the supported shapes (host checks).
-    constexpr int PPT = S2 ? 8 : (CK * SEGS + MF_THREADS - 1) / MF_THREADS;  // pieces per thread per stage
+    constexpr int PPT = S2 ? 8 : (CK * SEGS + THR - 1) / THR;  // pieces per thread per stage
 
 #ifdef QE_STAMP
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1557,7 +1562,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
     const int NT = min(NTP, P - p0);            // valid pixels of this tile (multiple of 4)
 
     uint8_t *Xs = smem;                                                   // [CK][RSTR]
-    constexpr int XS_BYTES = (CK * RSTR > 4 * 32 * 36 * 4) ? CK * RSTR : 4 * 32 * 36 * 4;  // image, later the epilogue patches
+    constexpr int XS_BYTES = (CK * RSTR > WM * WN * 32 * 36 * 4) ? CK * RSTR : WM * WN * 32 * 36 * 4;  // image, later the epilogue patches
     int *sxp = reinterpret_cast<int *>(smem + XS_BYTES);                  // [NTP], only when zw' != 0
 
     // ---- epilogue constants of this lane's output channel -----------------------------------
@@ -1581,7 +1586,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
     int plds[PPT];        // LDS byte offset, or -1 when the piece does not exist
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-        const int e = tid + MF_THREADS * i;
+        const int e = tid + THR * i;
         if constexpr (!S2) {
             const int c = e / SEGS, sg = e - c * SEGS;
             const int px = p0 + 16 * sg;
@@ -1631,8 +1636,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
     const int i16 = lane & 15;
     const int tr_base = (16 * h + (i16 >> 1)) * RSTR + 16 * ((lane >> 4) & 1) + 8 * (i16 & 1);
 
-    std::conditional_t<X4, uint2, uint4> d[PPT];
-    auto issue_x = [&](int s) __attribute__((always_inline)) {
+    using DT = std::conditional_t<X4, uint2, uint4>;
+    DT d[PPT];
+    auto issue_x = [&](int s, DT (&d)[PPT]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             const int cg = s * CK + pc[i];
@@ -1646,15 +1652,15 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
             }
         }
     };
-    issue_x(0);   // in flight while the zero-point test below synchronises the workgroup
+    issue_x(0, d);   // in flight while the zero-point test below synchronises the workgroup
 
     const bool need_sx = __syncthreads_or((oc < a.OC && zwp != 0.0f) ? 1 : 0) != 0;   // workgroup-uniform
     if (need_sx) {
-        for (int i = tid; i < NTP; i += MF_THREADS) sxp[i] = 0;
+        for (int i = tid; i < NTP; i += THR) sxp[i] = 0;
         __syncthreads();
     }
 
-    auto stage_x = [&](int s) __attribute__((always_inline)) {
+    auto stage_x = [&](int s, DT (&d)[PPT]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             uint32_t v0, v1, v2, v3;
@@ -1738,12 +1744,12 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
         }
         QE_ST(0);   // prologue / weight requests
         // (2) activations of this stage: registers -> LDS
-        stage_x(s);
+        stage_x(s, d);
         QE_ST(1);   // wait X + LDS writes
         __syncthreads();
         QE_ST(2);   // barrier 1
         // (3) next stage's activations in flight under the MFMA phase
-        if constexpr (decltype(prefetch)::value) issue_x(s + 1);
+        if constexpr (decltype(prefetch)::value) issue_x(s + 1, d);
         QE_ST(3);   // X(s+1) issue
         // (4) MFMA: A = transposed activation fragment (rows = pixels), B = weights (cols = oc)
 #pragma unroll
@@ -1766,9 +1772,55 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
         QE_ST(5);   // barrier 2
     };
 
+    if constexpr (NSTAGES > 0) {
+        static_assert(WRAW && !S2 && !X4, "deep-prefetch form: packed 8-bit weights, stride 1");
+        DT d2[PPT];
+        v4i wfa[NS], wfb[NS];
+        auto load_w = [&](int s, v4i (&wf)[NS]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) __builtin_memcpy(&wf[k], w_lane + (2 * (s * NS + k) + h) * 16, 16);   // IC == NSTAGES * CK: no padding
+        };
+        auto mma = [&](v4i (&wf)[NS]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                v4i f = wf[k];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f[j] ^= (int)0x80808080;
+                    swacc = __builtin_amdgcn_sdot4(f[j], 0x01010101, swacc, false);
+                }
+#pragma unroll
+                for (int t = 0; t < NIW; ++t) {
+                    const uint8_t *src = Xs + tr_base + (k * 32) * RSTR + (wn + t * WN) * 32;
+                    const v2i lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(src));
+                    const v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(src + 8 * RSTR));
+                    const v4i xf = {lo[0], lo[1], hi[0], hi[1]};
+                    acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xf, f, acc[t], 0, 0, 0);
+                }
+            }
+        };
+        if constexpr (NSTAGES > 1) issue_x(1, d2);
+        load_w(0, wfa);
+        QE_ST(0);
+#pragma unroll
+        for (int s = 0; s < NSTAGES; ++s) {
+            if (s & 1) stage_x(s, d2); else stage_x(s, d);
+            QE_ST(1);
+            __syncthreads();
+            QE_ST(2);
+            if (s + 2 < NSTAGES) { if (s & 1) issue_x(s + 2, d2); else issue_x(s + 2, d); }
+            if (s + 1 < NSTAGES) { if (s & 1) load_w(s + 1, wfa); else load_w(s + 1, wfb); }
+            QE_ST(3);
+            if (s & 1) mma(wfb); else mma(wfa);
+            QE_ST(4);
+            __syncthreads();
+            QE_ST(5);
+        }
+    } else {
     const int n_stages = (a.IC + CK - 1) / CK;
     for (int s = 0; s < n_stages - 1; ++s) stage(s, std::true_type{});
     stage(n_stages - 1, std::false_type{});
+    }
 
     // ---- epilogue: lane = output channel, 4 consecutive registers = 4 consecutive pixels ------
     const int sw_sum = swacc + __shfl_xor(swacc, 32);   // both channel halves
@@ -1829,7 +1881,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
         if (oc >= a.OC) bad = false;
         __syncthreads();
         constexpr int PPR = NTP / 16;                                          // 16-byte pieces per row
-        for (int e = tid; e < MT * PPR; e += MF_THREADS) {
+        for (int e = tid; e < MT * PPR; e += THR) {
             const int row = e / PPR, px = 16 * (e - row * PPR);
             const int oc_r = ot * MT + row;
             if (oc_r < a.OC && px < NT) {
@@ -1891,7 +1943,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_flat_kernel(const Mfm
     __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0): stores acknowledged
     QE_ST(7);       // store drain
     if (a.dbg != nullptr && lane == 0) {
-        unsigned long long *o = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 10;
+        unsigned long long *o = a.dbg + ((size_t)blockIdx.x * (WM * WN) + wave) * 10;
         for (int i = 0; i < 8; ++i) o[i] = st[i];
         o[8] = tprev - tstart;
         o[9] = tstart;

@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace qe {
 
@@ -360,6 +361,275 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a)
 }
 template <int NJ> constexpr size_t lin_lds_bytes() { return (size_t)L_RING * (LM + 64 * NJ) * LK + (LM + 64 * NJ) * sizeof(float4); }
 
+
+// ---------------------------------------------------------------------------------------------
+// The same GEMM on a 320 x 256 tile per CU: 512 threads = 2 x 4 waves, a wave owns 160 rows x 64 columns = 5 x 2 MFMA tiles
+// (160 accumulator registers, 7 fragments per 10 MFMAs).  Why: linear_mfma_kernel<4> runs TWO 128 x 256 workgroups per CU,
+// each fetching its own operand tiles -- (128 + 256) bytes per k for 128 x 256 products, twice: at the matrix pipe's full rate
+// that is 48 B/clk through a CU's 64 B/clk vector-memory path, before a single output byte is stored (stamps: 120 cycles to
+// ISSUE one of its LDS-DMA instructions, the issue time of a stage's six about what its sixteen MFMAs take).  One 320 x 256
+// tile moves (320 + 256) bytes per k for 2.5x the products: 28 B/clk at full rate.  320 rows because the row count that
+// matters (50,432 tokens of a ViT-B/16 batch) then makes 158 row tiles: 474 tiles of a 768-column layer are 1.85 rounds of
+// the 256 CUs (2 rounds, 92 % full) where 128- or 256-row tiles make 2.31 rounds (3 rounds, 77 % full).
+// Stage = 128 k of both operand tiles (72 KB), two buffers, the next stage requested right after the barrier that frees its
+// buffer (a full stage of MFMAs -- 40 per wave -- ahead of its use).  128 and not 64 deep because a row piece of a stage is
+// then one whole 128-byte cache line: with 64-byte pieces every line crosses the L2 -> L1 path twice (its second half a
+// stage later, after 36 KB of other lines have passed through the 32 KB L1), and that path, not the matrix pipe, is what
+// bounds this kernel (stamps of the 64-deep form: 150 cycles to issue one LDS-DMA instruction, 28 B/clk per CU).
+// One raw s_barrier per stage.  The row sums S_x and column sums S_w (v_dot4 on the fragments) are shared out: column quarter
+// wn sums k-step wn of every stage, row half wm every other k-step; the exact integer partials meet in LDS in the epilogue.
+// ---------------------------------------------------------------------------------------------
+constexpr int L8_TM = 320, L8_TN = 256, L8_RING = 2, L8_K = 128;
+constexpr int L8_STAGE = (L8_TM + L8_TN) * L8_K;        // 73,728 bytes
+constexpr int L8_PA = L8_TM * (L8_K / 16) / 512;        // A pieces per thread per stage (5)
+constexpr int L8_PB = L8_TN * (L8_K / 16) / 512;        // B pieces per thread per stage (4)
+constexpr size_t lin8_lds_bytes() { return (size_t)L8_RING * L8_STAGE + (L8_TM + L8_TN) * sizeof(float4); }
+
+__global__ __launch_bounds__(512, 1) void linear_mfma8_kernel(const LinArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lsm[];
+    float4 *rowc = reinterpret_cast<float4 *>(lsm + L8_RING * L8_STAGE);   // per batch row: sx, zx', S_x, K zx'
+    float4 *colc = rowc + L8_TM;                                           // per output column: sw, zw', bias, S_w
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int col = lane & 31, h = lane >> 5;
+#ifdef QE_STAMP
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = lin_stamp();
+    const unsigned long long tstart = tprev;
+#endif
+    const int n_ct = (a.O + L8_TN - 1) / L8_TN;
+    const int64_t bid = blockIdx.x;
+    const int ct = (int)(bid % n_ct);
+    const int64_t rt = bid / n_ct;
+    const int64_t m0 = rt * L8_TM;
+    const int n0 = ct * L8_TN;
+
+    // DMA pieces: LDS slot e = tid + 512 i <-> (row e >> 3, slot e & 7) receives k-piece (slot ^ ((row >> 1) & 7)) of that row:
+    // a wave-level instruction fetches 8 rows x 128 contiguous bytes = 8 whole cache lines.  ds_read_b128 banks are 256 bytes wide
+    // (two rows) and served in the 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): the 8 even and the 8 odd rows of
+    // a group have 8 different (row >> 1) & 7, so a group's 16 reads of one k-piece cover all 16 sixteen-byte slots.
+    const int slot = tid & 7;
+    const uint8_t *pa[L8_PA];
+    const uint8_t *pb[L8_PB];
+#pragma unroll
+    for (int i = 0; i < L8_PA; ++i) {
+        const int r = (tid + 512 * i) >> 3;
+        const int64_t row = (m0 + r < a.B) ? m0 + r : a.B - 1;
+        pa[i] = a.x + row * a.K + 16 * (slot ^ ((r >> 1) & 7));
+    }
+#pragma unroll
+    for (int i = 0; i < L8_PB; ++i) {
+        const int r = (tid + 512 * i) >> 3;
+        const int c = (n0 + r < a.O) ? n0 + r : a.O - 1;
+        pb[i] = a.w + (int64_t)c * a.K + 16 * (slot ^ ((r >> 1) & 7));
+    }
+    // piece q of a stage: 0..4 = A, 5..8 = B.  The requests of stage s + 1 are spread over the k-steps of stage s: issued in one
+    // burst behind the barrier, the 72 instructions of a workgroup queue at the CU's one address path and every wave sits in
+    // its issue slot (180 cycles per instruction, stamps) with no MFMA behind it -- 1,600 cycles of a 7,300-cycle stage.
+    auto issue_piece = [&](int stage, auto q_tag) __attribute__((always_inline)) {
+        constexpr int q = decltype(q_tag)::value;
+        uint8_t *buf = lsm + (stage % L8_RING) * L8_STAGE;
+        const int k0 = stage * L8_K;
+        if constexpr (q < L8_PA)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pa[q] + k0),
+                                             (__attribute__((address_space(3))) void *)(buf + (512 * q + 64 * wave) * 16), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pb[q - L8_PA] + k0),
+                                             (__attribute__((address_space(3))) void *)(buf + L8_TM * L8_K + (512 * (q - L8_PA) + 64 * wave) * 16), 16, 0, 0);
+    };
+#define QE_L8_ISSUE(ST, Q) issue_piece(ST, std::integral_constant<int, Q>{})
+    auto issue = [&](int stage) __attribute__((always_inline)) {
+        QE_L8_ISSUE(stage, 0); QE_L8_ISSUE(stage, 1); QE_L8_ISSUE(stage, 2); QE_L8_ISSUE(stage, 3); QE_L8_ISSUE(stage, 4);
+        QE_L8_ISSUE(stage, 5); QE_L8_ISSUE(stage, 6); QE_L8_ISSUE(stage, 7); QE_L8_ISSUE(stage, 8);
+    };
+    const int n_stages = a.K / L8_K;
+    issue(0);                                             // in flight while the epilogue constants are fetched
+
+    const float dx = (a.x_sign ? 0.0f : 128.0f), dw = (a.w_sign ? 0.0f : 128.0f);   // a = q - d  ->  z' = z + d
+    if (tid < L8_TM) {
+        const int64_t row = (m0 + tid < a.B) ? m0 + tid : a.B - 1;
+        const float sx = a.x_per_tensor ? a.x_scale[0] : a.x_scale[row];
+        const float zxp = (a.x_per_tensor ? a.x_zero[0] : a.x_zero[row]) + dx;
+        rowc[tid] = make_float4(sx, zxp, 0.0f, (float)a.K * zxp);
+    }
+    if (tid < L8_TN) {
+        const int cc = (n0 + tid < a.O) ? n0 + tid : a.O - 1;
+        colc[tid] = make_float4(a.w_per_tensor ? a.w_scale[0] : a.w_scale[cc],
+                                (a.w_per_tensor ? a.w_zero[0] : a.w_zero[cc]) + dw, a.bias ? a.bias[cc] : 0.0f, 0.0f);
+    }
+
+    v16i acc[5][2];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+    int sxa[5] = {0, 0, 0, 0, 0};  // this lane's share of S_x of its five row tiles (row = col, k half h) over ITS k-steps (ks == wn)
+    int swa[2] = {0, 0};           // ... of S_w of its two column tiles over its k-steps (ks & 1 == wm)
+
+    const int swz = (col >> 1) & 7;                       // (row >> 1) & 7 of this lane's fragment rows (row = 32 t + col)
+    const int a_off = (wm * 160 + col) * L8_K, b_off = L8_TM * L8_K + (wn * 64 + col) * L8_K;
+    LIN_ST(0);   // prologue
+    for (int s = 0; s < n_stages; ++s) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);               // vmcnt(0): this wave's pieces of stage s (the only ones in flight) landed
+        LIN_ST(1);   // wait for the stage's DMA
+        __builtin_amdgcn_s_barrier();                     // ... every wave's; and every wave is done with stage s - 1: its buffer is free
+        LIN_ST(2);   // barrier
+        const bool more = s + 1 < n_stages;
+        LIN_ST(3);
+        const uint8_t *buf = lsm + (s % L8_RING) * L8_STAGE;
+        // k-step pipeline of ONE wave: the B fragments of k-step ks + 1 are requested while the MFMAs of k-step ks run; the A
+        // fragments are waited for one by one (counted lgkmcnt), each recoded right in front of its two MFMAs, so their LDS
+        // latency and the recoding VALU work sit under the MFMAs of the rows before them (sched_group_barrier pins that order:
+        // left alone, hipcc hoists all 28 v_xor in front of the first MFMA behind one lgkmcnt(0)).
+        v4i fb[2], fbn[2];
+        {
+            const int po0 = 16 * (h ^ swz);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const v4i *>(buf + b_off + j * 32 * L8_K + po0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < L8_K / 32; ++ks) {
+            if (more) {
+                if (ks == 0) { QE_L8_ISSUE(s + 1, 0); QE_L8_ISSUE(s + 1, 1); QE_L8_ISSUE(s + 1, 2); }
+                if (ks == 1) { QE_L8_ISSUE(s + 1, 3); QE_L8_ISSUE(s + 1, 4); }
+                if (ks == 2) { QE_L8_ISSUE(s + 1, 5); QE_L8_ISSUE(s + 1, 6); }
+                if (ks == 3) { QE_L8_ISSUE(s + 1, 7); QE_L8_ISSUE(s + 1, 8); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int po = 16 * ((2 * ks + h) ^ swz);
+            v4i fa[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) fa[i] = *reinterpret_cast<const v4i *>(buf + a_off + i * 32 * L8_K + po);
+            if (ks + 1 < L8_K / 32) {
+                const int pon = 16 * ((2 * (ks + 1) + h) ^ swz);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fbn[j] = *reinterpret_cast<const v4i *>(buf + b_off + j * 32 * L8_K + pon);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fb[j][q] ^= (int)0x80808080;
+            if ((ks & 1) == wm) {                         // S_w: the two row halves take alternate k-steps (wave-uniform)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) swa[j] = __builtin_amdgcn_sdot4(fb[j][q], 0x01010101, swa[j], false);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fa[i][q] ^= (int)0x80808080;          // u - 128: signed q, or unsigned q - 128
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // 4 VALU (recode of row tile i)
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == wn) {                               // S_x: column quarter wn takes k-step wn of every stage (wave-uniform)
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sxa[i] = __builtin_amdgcn_sdot4(fa[i][q], 0x01010101, sxa[i], false);
+            }
+            if (ks + 1 < L8_K / 32) { fb[0] = fbn[0]; fb[1] = fbn[1]; }
+        }
+        LIN_ST(4);   // fragment reads + MFMA
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------
+    __syncthreads();                                      // every wave is done with the operand ring; the constants are in place
+    // partial sums (exact integers) meet in LDS: S_x from the four column quarters, S_w from the two row halves
+    int *part = reinterpret_cast<int *>(lsm);             // [4][320] S_x partials, then [2][256] S_w partials
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int sx_sum = sxa[i] + __shfl_xor(sxa[i], 32);
+        if (h == 0) part[wn * L8_TM + wm * 160 + i * 32 + col] = sx_sum;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int sw_sum = swa[j] + __shfl_xor(swa[j], 32);
+        if (h == 0) part[4 * L8_TM + wm * L8_TN + wn * 64 + j * 32 + col] = sw_sum;
+    }
+    __syncthreads();
+    if (tid < L8_TM) rowc[tid].z = (float)(part[tid] + part[L8_TM + tid] + part[2 * L8_TM + tid] + part[3 * L8_TM + tid]);
+    if (tid < L8_TN) colc[tid].w = (float)(part[4 * L8_TM + tid] + part[4 * L8_TM + L8_TN + tid]);
+    __syncthreads();                                      // sums visible
+    const bool vec4 = (a.O & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
+    float *patch = reinterpret_cast<float *>(lsm) + wave * (32 * 36);
+    const int rrow = lane >> 3, rq = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int cl = wn * 64 + j * 32 + col;
+            const int c = n0 + cl;
+            const float4 cc = colc[cl];                   // sw, zw', bias, S_w
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm * 160 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float4 rc = rowc[rl];
+                float t = (float)acc[i][j][r];
+                t = fmaf(cc.y, rc.z, t);
+                t = fmaf(rc.y, cc.w, t);
+                t = fmaf(rc.w, cc.y, t);
+                v[r] = fmaf(rc.x * cc.x, t, cc.z);
+            }
+            const int64_t row0 = m0 + wm * 160 + i * 32;
+            if (vec4) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + col] = v[r];
+                __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): same wave wrote and reads
+                const int c4 = n0 + wn * 64 + j * 32 + 4 * rq;
+                if (row0 + 32 <= a.B && n0 + wn * 64 + j * 32 + 32 <= a.O) {   // wave-uniform: plain stores
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int rt8 = 8 * k + rrow;
+                        const float4 o4 = *reinterpret_cast<const float4 *>(patch + rt8 * 36 + 4 * rq);
+                        *reinterpret_cast<float4 *>(a.out + (row0 + rt8) * a.O + c4) = o4;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int rt8 = 8 * k + rrow;
+                        const float4 o4 = *reinterpret_cast<const float4 *>(patch + rt8 * 36 + 4 * rq);
+                        const int64_t row = row0 + rt8;
+                        if (row < a.B && c4 < a.O) *reinterpret_cast<float4 *>(a.out + row * a.O + c4) = o4;
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);   // reads done before the next tile overwrites the patch
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < a.B && c < a.O) a.out[row * a.O + c] = v[r];
+                }
+            }
+        }
+    }
+#ifdef QE_STAMP
+    LIN_ST(6);   // epilogue issue
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    LIN_ST(7);   // store drain
+    if (a.dbg != nullptr && lane == 0) {
+        unsigned long long *o = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 10;
+        for (int i = 0; i < 8; ++i) o[i] = st[i];
+        o[8] = tprev - tstart;
+        o[9] = tstart;
+    }
+#endif
+}
+
 static int check_lin_q(const qe_qparam *q, int64_t n_expected)
 {
     if (q == nullptr || q->data == nullptr || q->scale == nullptr || q->zero == nullptr) return QE_ERR_ARG;
@@ -415,6 +685,18 @@ extern "C" int qe_quantlinear(const qe_qparam *x, const qe_qparam *w, const floa
             hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lin_lds_bytes<2>()) == hipSuccess;
         (void)raised;
+        // 320 x 256 tiles, one 8-wave workgroup per CU: when the problem fills the chip at least once with them.  QE_LIN8=0: never, 1: always
+        bool big = ((B + L8_TM - 1) / L8_TM) * ((O + L8_TN - 1) / L8_TN) >= kNumCU;
+        if ((K % L8_K) != 0) big = false;                  // whole 128-deep stages (else the 64-deep kernel below)
+        if (const char *e = env_get("QE_LIN8")) big = atoi(e) != 0 && (K % L8_K) == 0;
+        if (big && !env_get("QE_LIN_NJ")) {
+            static const bool raised8 = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_mfma8_kernel),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin8_lds_bytes()) == hipSuccess;
+            (void)raised8;
+            const int64_t blocks8 = ((B + L8_TM - 1) / L8_TM) * ((O + L8_TN - 1) / L8_TN);
+            if (blocks8 > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
+            hipLaunchKernelGGL(linear_mfma8_kernel, dim3((unsigned)blocks8), dim3(512), lin8_lds_bytes(), s, a);
+        } else
         if (nj == 4) hipLaunchKernelGGL(linear_mfma_kernel<4>, dim3((unsigned)blocks), dim3(256), lin_lds_bytes<4>(), s, a);
         else         hipLaunchKernelGGL(linear_mfma_kernel<2>, dim3((unsigned)blocks), dim3(256), lin_lds_bytes<2>(), s, a);
     } else {

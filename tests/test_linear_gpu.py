@@ -217,3 +217,29 @@ def test_deep_reductions_leave_the_int32_kernel():
     xq, wq = capi.qparam(buf, 8, True, one, one), capi.qparam(buf, 8, True, one, one)
     assert capi.linear_path(xq, wq, 4, (1 << 17) - 64, 4) == 1
     assert capi.linear_path(xq, wq, 4, 1 << 17, 4) == 0
+
+
+def test_big_tile_kernel_forced(engine, monkeypatch):
+    """linear_mfma8_kernel (320 x 256 tiles, 8 waves) forced onto the sweep shapes it is eligible for (ragged row and column
+    counts, per-row activation scales, asymmetric operands, 1 to 48 stages): against the oracle and, bit for bit, against
+    the 128 x 256 kernel (same integer sums, same epilogue operation order)."""
+    from quantize_amd import capi as _capi
+    rng = np.random.RandomState(11)
+    k = 0
+    for shp in [(64, 768, 130), (129, 3072, 96), (200, 1024, 512), (700, 128, 520), (321, 256, 256), (1, 128, 4), (130, 64, 257)]:
+        for (wsgn, asgn) in [(1, 1), (0, 0), (1, 0)]:
+            k += 1
+            c = _random_case(rng, *shp, 8, wsgn, 8, asgn, w_pc=k % 2 == 0, a_pr=k % 3 != 0, zeros=k % 4 != 0, bias=k % 5 != 0)
+            monkeypatch.setenv("QE_LIN8", "1")
+            _capi.reload_env()
+            y8, path = _run(engine, c, True)
+            torch.cuda.synchronize()
+            monkeypatch.setenv("QE_LIN8", "0")
+            _capi.reload_env()
+            y4, _ = _run(engine, c, True)
+            torch.cuda.synchronize()
+            assert path == 1
+            _close(y8.cpu().numpy(), c["o64"], c["o32"], "big tile %s" % (shp,), c["fma"])
+            assert torch.equal(y8, y4), shp
+    monkeypatch.delenv("QE_LIN8")
+    _capi.reload_env()

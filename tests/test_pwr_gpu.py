@@ -114,3 +114,34 @@ def test_pwr_batch256_independence(engine, monkeypatch):
         # and against plain integer arithmetic on one image
         ref = torch.nn.functional.conv2d(xq[255:256].double(), wq.double()) * (2e-3 * ws.double().view(1, oc, 1, 1)) + b.double().view(1, oc, 1, 1)
         assert (full[255:256].double() - ref).abs().max().item() <= 1e-5
+
+
+WIDE_SHAPES = [
+    # N, IC, H, W, OC, K, stride, pad -- deep 1x1 reductions into a multiple of 256 output channels (8-wave flat kernel)
+    (2, 1024, 14, 14, 256, 1, 1, 0),    # ResNet-50 layer3 reduction: whole-plane tiles of 224 slots
+    (1, 1024, 14, 14, 512, 1, 1, 0),    # layer4.0.conv1: two channel tiles
+    (2, 512, 28, 28, 256, 1, 1, 0),     # layer3.0.conv1: 160-pixel tiles (5 column tiles), ragged last tile
+    (1, 512, 14, 14, 1024, 1, 1, 0),    # the dense form of layer3's downsample branch
+    (3, 640, 12, 12, 256, 1, 1, 0),     # 144-pixel planes, 5 stages of 128 channels
+    (2, 512, 28, 28, 1024, 1, 2, 0),    # strided: gather pass + the dense problem above
+]
+
+
+@pytest.mark.parametrize("flat8", ["1", "0"])
+def test_wide_flat_kernel_vs_oracle(engine, flat8):
+    """conv_mfma_flat_kernel<8, 1, NIW, 4>: 256 output channels per workgroup (launch_conv_mfma: wide8) against the oracle and,
+    bit for bit, against the 4-wave instances (same integer sums, same epilogue operation order)."""
+    rng = np.random.RandomState(808)
+
+    def run():
+        for shp in WIDE_SHAPES:
+            for (asgn, zeros, w_pc, bias) in [(1, False, True, True), (0, True, True, True), (1, True, False, False)]:
+                case = _random_case(rng, *shp, 8, 1 if asgn else 0, 8, asgn, w_pc=w_pc, a_pc=False, zeros=zeros, bias=bias)
+                y, o32, o64 = _run_case(engine, case, via_capi=True)
+                assert case["path"] == 1
+                _assert_conv_close(y, o64, o32, "flat8=%s %s asgn=%d zeros=%s" % (flat8, shp, asgn, zeros), case["fma"])
+                if not zeros:
+                    assert np.abs(y.astype(np.float64) - o64).max() <= 1e-5
+                y_other = _with_env({"QE_FLAT8": "0" if flat8 == "1" else "1"}, lambda: _run_case(engine, case, via_capi=True)[0])
+                assert np.array_equal(y, y_other), "wide and 4-wave flat kernels differ: %s" % (shp,)
+    _with_env({"QE_FLAT8": flat8}, run)

@@ -1,5 +1,7 @@
 set -o pipefail
-timeout -k 10 600 python -m pytest tests/test_requant_gpu.py -x -q > gpurun_out/r03u_rq_test.txt 2>&1; rc=$?; tail -5 gpurun_out/r03u_rq_test.txt; [ $rc -eq 0 ] || exit 1
-timeout -k 10 300 python bench.py --steps 5 --warmup 2 --per-layer --cold --no-cpu-baseline --fused-requant --layers 0,2,6,12,16,19,25,29,32,44,48,51,52 > gpurun_out/r03u_fused_pl.json 2> gpurun_out/r03u_fused_pl.err; grep -E "^ *[0-9]+ (layer|conv)|sum of" gpurun_out/r03u_fused_pl.err
-timeout -k 10 200 python bench.py --steps 100 --warmup 5 --no-cpu-baseline --fused-requant > gpurun_out/r03u_fused.json 2> gpurun_out/r03u_fused.err; python -c "
-import json;j=json.load(open('gpurun_out/r03u_fused.json'));print(j['value'], j['ms_per_step'], j['roofline']['conv_stack_ms'])"
+timeout -k 10 600 python -m pytest tests/test_linear_gpu.py -x -q > gpurun_out/r03x_lin_test.txt 2>&1; rc=$?; tail -15 gpurun_out/r03x_lin_test.txt; [ $rc -eq 0 ] || exit 1
+for v in 0 1; do
+QE_LIN8=$v timeout -k 10 200 python tools/bench_linear.py --steps 5 > gpurun_out/r03x_linear_$v.json; python -c "
+import json;j=json.load(open('gpurun_out/r03x_linear_$v.json'));print('QE_LIN8=$v', j['value'], j['ms_per_step'], j.get('per_shape') or j)"
+done
+QE_LIB=quantize_amd/_ext/libqe_hip_stamp.so timeout -k 10 120 python tools/stamp_linear.py 50432 768 768 50432 768 3072 50432 3072 768 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r03x_stamp_linear8b.txt
