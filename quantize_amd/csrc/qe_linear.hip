@@ -379,21 +379,31 @@ template <int NJ> constexpr size_t lin_lds_bytes() { return (size_t)L_RING * (LM
 // One raw s_barrier per stage.  The row sums S_x and column sums S_w (v_dot4 on the fragments) are shared out: column quarter
 // wn sums k-step wn of every stage, row half wm every other k-step; the exact integer partials meet in LDS in the epilogue.
 // ---------------------------------------------------------------------------------------------
-constexpr int L8_TM = 320, L8_TN = 256, L8_RING = 2, L8_K = 128;
-constexpr int L8_STAGE = (L8_TM + L8_TN) * L8_K;        // 73,728 bytes
-constexpr int L8_PA = L8_TM * (L8_K / 16) / 512;        // A pieces per thread per stage (5)
-constexpr int L8_PB = L8_TN * (L8_K / 16) / 512;        // B pieces per thread per stage (4)
-constexpr size_t lin8_lds_bytes() { return (size_t)L8_RING * L8_STAGE + (L8_TM + L8_TN) * sizeof(float4); }
+constexpr int L8_TN = 256, L8_K = 128;
+// WMW = 2: the 8-wave form above (tile 320 x 256, two stage buffers, one workgroup per CU).
+// WMW = 1: 4 waves, tile 160 x 256, ONE stage buffer (52 KB), two workgroups per CU: a workgroup waits out its own operand
+// fetch, but the other one computes or stores meanwhile -- for the write-bound shapes (K = 768: six stages, then 164 KB of
+// output per tile), where the 8-wave form has nothing to run beside its epilogue.
+template <int WMW> struct L8Geom {
+    static constexpr int THREADS = 256 * WMW, TM = 160 * WMW, RING = WMW == 2 ? 2 : 1;
+    static constexpr int STAGE = (TM + L8_TN) * L8_K;
+    static constexpr int PA = TM * (L8_K / 16) / THREADS;      // A pieces per thread per stage (5)
+    static constexpr int PB = L8_TN * (L8_K / 16) / THREADS;   // B pieces per thread per stage (4 | 8)
+    static constexpr size_t LDS = (size_t)RING * STAGE + (TM + L8_TN) * sizeof(float4);
+};
 
-__global__ __launch_bounds__(512, 1) void linear_mfma8_kernel(const LinArgs a)
+template <int WMW>
+__global__ __launch_bounds__(256 * WMW, WMW == 2 ? 1 : 2) void linear_mfma8_kernel(const LinArgs a)
 {
+    using G = L8Geom<WMW>;
+    constexpr int L8_TM = G::TM, L8_RING = G::RING, L8_STAGE = G::STAGE, L8_PA = G::PA, L8_PB = G::PB, THR = G::THREADS;
     extern __shared__ __attribute__((aligned(16))) uint8_t lsm[];
     float4 *rowc = reinterpret_cast<float4 *>(lsm + L8_RING * L8_STAGE);   // per batch row: sx, zx', S_x, K zx'
     float4 *colc = rowc + L8_TM;                                           // per output column: sw, zw', bias, S_w
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = WMW == 2 ? (wave & 1) : 0, wn = WMW == 2 ? (wave >> 1) : wave;
     const int col = lane & 31, h = lane >> 5;
 #ifdef QE_STAMP
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -412,19 +422,18 @@ __global__ __launch_bounds__(512, 1) void linear_mfma8_kernel(const LinArgs a)
     // (two rows) and served in the 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): the 8 even and the 8 odd rows of
     // a group have 8 different (row >> 1) & 7, so a group's 16 reads of one k-piece cover all 16 sixteen-byte slots.
     const int slot = tid & 7;
-    const uint8_t *pa[L8_PA];
-    const uint8_t *pb[L8_PB];
+    uint32_t pa[L8_PA], pb[L8_PB];                         // byte offsets from a.x / a.w (host: B K and O K below 2^32)
 #pragma unroll
     for (int i = 0; i < L8_PA; ++i) {
-        const int r = (tid + 512 * i) >> 3;
+        const int r = (tid + THR * i) >> 3;
         const int64_t row = (m0 + r < a.B) ? m0 + r : a.B - 1;
-        pa[i] = a.x + row * a.K + 16 * (slot ^ ((r >> 1) & 7));
+        pa[i] = (uint32_t)(row * a.K + 16 * (slot ^ ((r >> 1) & 7)));
     }
 #pragma unroll
     for (int i = 0; i < L8_PB; ++i) {
-        const int r = (tid + 512 * i) >> 3;
+        const int r = (tid + THR * i) >> 3;
         const int c = (n0 + r < a.O) ? n0 + r : a.O - 1;
-        pb[i] = a.w + (int64_t)c * a.K + 16 * (slot ^ ((r >> 1) & 7));
+        pb[i] = (uint32_t)((int64_t)c * a.K + 16 * (slot ^ ((r >> 1) & 7)));
     }
     // piece q of a stage: 0..4 = A, 5..8 = B.  The requests of stage s + 1 are spread over the k-steps of stage s: issued in one
     // burst behind the barrier, the 72 instructions of a workgroup queue at the CU's one address path and every wave sits in
@@ -433,17 +442,19 @@ __global__ __launch_bounds__(512, 1) void linear_mfma8_kernel(const LinArgs a)
         constexpr int q = decltype(q_tag)::value;
         uint8_t *buf = lsm + (stage % L8_RING) * L8_STAGE;
         const int k0 = stage * L8_K;
-        if constexpr (q < L8_PA)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pa[q] + k0),
-                                             (__attribute__((address_space(3))) void *)(buf + (512 * q + 64 * wave) * 16), 16, 0, 0);
+        if constexpr (q >= L8_PA + L8_PB) { }
+        else if constexpr (q < L8_PA)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.x + (pa[q] + (uint32_t)k0)),
+                                             (__attribute__((address_space(3))) void *)(buf + (THR * q + 64 * wave) * 16), 16, 0, 0);
         else
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pb[q - L8_PA] + k0),
-                                             (__attribute__((address_space(3))) void *)(buf + L8_TM * L8_K + (512 * (q - L8_PA) + 64 * wave) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.w + (pb[q - L8_PA] + (uint32_t)k0)),
+                                             (__attribute__((address_space(3))) void *)(buf + L8_TM * L8_K + (THR * (q - L8_PA) + 64 * wave) * 16), 16, 0, 0);
     };
 #define QE_L8_ISSUE(ST, Q) issue_piece(ST, std::integral_constant<int, Q>{})
     auto issue = [&](int stage) __attribute__((always_inline)) {
         QE_L8_ISSUE(stage, 0); QE_L8_ISSUE(stage, 1); QE_L8_ISSUE(stage, 2); QE_L8_ISSUE(stage, 3); QE_L8_ISSUE(stage, 4);
         QE_L8_ISSUE(stage, 5); QE_L8_ISSUE(stage, 6); QE_L8_ISSUE(stage, 7); QE_L8_ISSUE(stage, 8);
+        if constexpr (L8_PA + L8_PB > 9) { QE_L8_ISSUE(stage, 9); QE_L8_ISSUE(stage, 10); QE_L8_ISSUE(stage, 11); QE_L8_ISSUE(stage, 12); }
     };
     const int n_stages = a.K / L8_K;
     issue(0);                                             // in flight while the epilogue constants are fetched
@@ -479,7 +490,7 @@ __global__ __launch_bounds__(512, 1) void linear_mfma8_kernel(const LinArgs a)
         LIN_ST(1);   // wait for the stage's DMA
         __builtin_amdgcn_s_barrier();                     // ... every wave's; and every wave is done with stage s - 1: its buffer is free
         LIN_ST(2);   // barrier
-        const bool more = s + 1 < n_stages;
+        const bool more = L8_RING == 2 && s + 1 < n_stages;   // one buffer: the next stage is requested behind the barrier at the loop's end
         LIN_ST(3);
         const uint8_t *buf = lsm + (s % L8_RING) * L8_STAGE;
         // k-step pipeline of ONE wave: the B fragments of k-step ks + 1 are requested while the MFMAs of k-step ks run; the A
@@ -514,7 +525,7 @@ __global__ __launch_bounds__(512, 1) void linear_mfma8_kernel(const LinArgs a)
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) fb[j][q] ^= (int)0x80808080;
-            if ((ks & 1) == wm) {                         // S_w: the two row halves take alternate k-steps (wave-uniform)
+            if (WMW == 1 || (ks & 1) == wm) {             // S_w: the two row halves take alternate k-steps (wave-uniform)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -544,6 +555,13 @@ __global__ __launch_bounds__(512, 1) void linear_mfma8_kernel(const LinArgs a)
             if (ks + 1 < L8_K / 32) { fb[0] = fbn[0]; fb[1] = fbn[1]; }
         }
         LIN_ST(4);   // fragment reads + MFMA
+        if constexpr (L8_RING == 1) {
+            if (s + 1 < n_stages) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): this wave's fragment reads are done
+                __builtin_amdgcn_s_barrier();             // every wave's: the one buffer is free
+                issue(s + 1);
+            }
+        }
     }
 
     // ---- epilogue ------------------------------------------------------------------------------
@@ -562,58 +580,86 @@ __global__ __launch_bounds__(512, 1) void linear_mfma8_kernel(const LinArgs a)
     }
     __syncthreads();
     if (tid < L8_TM) rowc[tid].z = (float)(part[tid] + part[L8_TM + tid] + part[2 * L8_TM + tid] + part[3 * L8_TM + tid]);
-    if (tid < L8_TN) colc[tid].w = (float)(part[4 * L8_TM + tid] + part[4 * L8_TM + L8_TN + tid]);
+    if (tid < L8_TN) colc[tid].w = (float)(part[4 * L8_TM + tid] + (WMW == 2 ? part[4 * L8_TM + L8_TN + tid] : 0));
     __syncthreads();                                      // sums visible
     const bool vec4 = (a.O & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
-    float *patch = reinterpret_cast<float *>(lsm) + wave * (32 * 36);
+    // Two patches per wave (the operand buffers are free now): tile t + 1 is converted while tile t's patch round trip is in
+    // flight.  A wave's own LDS operations complete in order, so its reads see its writes and a later tile's writes cannot
+    // overtake the reads of the tile before -- no lgkmcnt drain between them (the 64 x 64-deep form drains twice per tile).
+    float *patch0 = reinterpret_cast<float *>(lsm) + wave * (2 * 32 * 36);
     const int rrow = lane >> 3, rq = lane & 7;
+    // symmetric operands (zx' = 0 for the wave's 160 rows, zw' = 0 for its 64 columns): out = bias + (sx sw) S_aw -- the three
+    // correction terms of the general form are exact zeros there, so both forms give the same bits; no per-row constants read
+    bool sym;
+    {
+        bool nz = false;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+        for (int q = 0; q < 3; ++q) { const int rr = lane + 64 * q; if (rr < 160) nz |= rowc[wm * 160 + rr].y != 0.0f; }
+        nz |= colc[wn * 64 + lane].y != 0.0f;
+        sym = __builtin_amdgcn_ballot_w64(nz) == 0ull;
+    }
+    const float sx_all = a.x_scale[0];
+    const bool fast = sym && a.x_per_tensor;
+    auto convert = [&](int i, int j, float (&v)[16]) __attribute__((always_inline)) {
+        const float4 cc = colc[wn * 64 + j * 32 + col];   // sw, zw', bias, S_w
+        if (fast) {
+            const float al = sx_all * cc.x;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int cl = wn * 64 + j * 32 + col;
-            const int c = n0 + cl;
-            const float4 cc = colc[cl];                   // sw, zw', bias, S_w
-            float v[16];
+            for (int r = 0; r < 16; ++r) v[r] = fmaf(al, (float)acc[i][j][r], cc.z);
+        } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int rl = wm * 160 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float4 rc = rowc[rl];
+                const float4 rc = rowc[wm * 160 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
                 float t = (float)acc[i][j][r];
                 t = fmaf(cc.y, rc.z, t);
                 t = fmaf(rc.y, cc.w, t);
                 t = fmaf(rc.w, cc.y, t);
                 v[r] = fmaf(rc.x * cc.x, t, cc.z);
             }
-            const int64_t row0 = m0 + wm * 160 + i * 32;
-            if (vec4) {
+        }
+    };
+    auto flush = [&](int i, int j, const float *patch) __attribute__((always_inline)) {
+        const int64_t row0 = m0 + wm * 160 + i * 32;
+        const int c4 = n0 + wn * 64 + j * 32 + 4 * rq;
+        if (row0 + 32 <= a.B && n0 + wn * 64 + j * 32 + 32 <= a.O) {   // wave-uniform: plain stores
 #pragma unroll
-                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + col] = v[r];
-                __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): same wave wrote and reads
-                const int c4 = n0 + wn * 64 + j * 32 + 4 * rq;
-                if (row0 + 32 <= a.B && n0 + wn * 64 + j * 32 + 32 <= a.O) {   // wave-uniform: plain stores
+            for (int k = 0; k < 4; ++k) {
+                const int rt8 = 8 * k + rrow;
+                const float4 o4 = *reinterpret_cast<const float4 *>(patch + rt8 * 36 + 4 * rq);
+                *reinterpret_cast<float4 *>(a.out + (row0 + rt8) * a.O + c4) = o4;
+            }
+        } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int rt8 = 8 * k + rrow;
-                        const float4 o4 = *reinterpret_cast<const float4 *>(patch + rt8 * 36 + 4 * rq);
-                        *reinterpret_cast<float4 *>(a.out + (row0 + rt8) * a.O + c4) = o4;
-                    }
-                } else {
+            for (int k = 0; k < 4; ++k) {
+                const int rt8 = 8 * k + rrow;
+                const float4 o4 = *reinterpret_cast<const float4 *>(patch + rt8 * 36 + 4 * rq);
+                const int64_t row = row0 + rt8;
+                if (row < a.B && c4 < a.O) *reinterpret_cast<float4 *>(a.out + row * a.O + c4) = o4;
+            }
+        }
+    };
+    if (vec4) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int rt8 = 8 * k + rrow;
-                        const float4 o4 = *reinterpret_cast<const float4 *>(patch + rt8 * 36 + 4 * rq);
-                        const int64_t row = row0 + rt8;
-                        if (row < a.B && c4 < a.O) *reinterpret_cast<float4 *>(a.out + row * a.O + c4) = o4;
-                    }
-                }
-                __builtin_amdgcn_s_waitcnt(0xc07f);   // reads done before the next tile overwrites the patch
-            } else {
+        for (int t = 0; t < 10; ++t) {
+            float v[16];
+            convert(t >> 1, t & 1, v);
+            if (t > 0) flush((t - 1) >> 1, (t - 1) & 1, patch0 + ((t - 1) & 1) * (32 * 36));
+            float *pw = patch0 + (t & 1) * (32 * 36);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (row < a.B && c < a.O) a.out[row * a.O + c] = v[r];
-                }
+            for (int r = 0; r < 16; ++r) pw[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + col] = v[r];
+        }
+        flush(4, 1, patch0 + (32 * 36));
+    } else {
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            const int i = t >> 1, j = t & 1;
+            float v[16];
+            convert(i, j, v);
+            const int c = n0 + wn * 64 + j * 32 + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wm * 160 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < a.B && c < a.O) a.out[row * a.O + c] = v[r];
             }
         }
     }
@@ -622,7 +668,7 @@ __global__ __launch_bounds__(512, 1) void linear_mfma8_kernel(const LinArgs a)
     __builtin_amdgcn_s_waitcnt(0x0f70);
     LIN_ST(7);   // store drain
     if (a.dbg != nullptr && lane == 0) {
-        unsigned long long *o = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 10;
+        unsigned long long *o = a.dbg + ((size_t)blockIdx.x * (4 * WMW) + wave) * 10;
         for (int i = 0; i < 8; ++i) o[i] = st[i];
         o[8] = tprev - tstart;
         o[9] = tstart;
@@ -685,17 +731,26 @@ extern "C" int qe_quantlinear(const qe_qparam *x, const qe_qparam *w, const floa
             hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lin_lds_bytes<2>()) == hipSuccess;
         (void)raised;
-        // 320 x 256 tiles, one 8-wave workgroup per CU: when the problem fills the chip at least once with them.  QE_LIN8=0: never, 1: always
-        bool big = ((B + L8_TM - 1) / L8_TM) * ((O + L8_TN - 1) / L8_TN) >= kNumCU;
-        if ((K % L8_K) != 0) big = false;                  // whole 128-deep stages (else the 64-deep kernel below)
-        if (const char *e = env_get("QE_LIN8")) big = atoi(e) != 0 && (K % L8_K) == 0;
-        if (big && !env_get("QE_LIN_NJ")) {
-            static const bool raised8 = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_mfma8_kernel),
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin8_lds_bytes()) == hipSuccess;
+        // 128-deep stages: 320 x 256 tiles (one 8-wave workgroup per CU) when the reduction is deep, 160 x 256 tiles (two 4-wave
+        // workgroups per CU) when the layer is bound by its stores (K <= 1024) -- either when the problem fills the chip with
+        // them.  QE_LIN8=0: never, 1: the 8-wave form, 2: the 4-wave form (tuning / tests)
+        int big = 0;
+        if ((K % L8_K) == 0 && B * (int64_t)K < (1ll << 32) && (int64_t)O * K < (1ll << 32)) {
+            if (K > 1024 && ((B + 319) / 320) * ((O + L8_TN - 1) / L8_TN) >= kNumCU) big = 1;
+            else if (K <= 1024 && ((B + 159) / 160) * ((O + L8_TN - 1) / L8_TN) >= 2 * kNumCU) big = 2;
+            if (const char *e = env_get("QE_LIN8")) big = atoi(e);
+            if (big < 0 || big > 2) big = 0;
+        }
+        if (big != 0 && !env_get("QE_LIN_NJ")) {
+            static const bool raised8 =
+                hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_mfma8_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L8Geom<2>::LDS) == hipSuccess &&
+                hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_mfma8_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L8Geom<1>::LDS) == hipSuccess;
             (void)raised8;
-            const int64_t blocks8 = ((B + L8_TM - 1) / L8_TM) * ((O + L8_TN - 1) / L8_TN);
+            const int tm = big == 1 ? 320 : 160;
+            const int64_t blocks8 = ((B + tm - 1) / tm) * ((O + L8_TN - 1) / L8_TN);
             if (blocks8 > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
-            hipLaunchKernelGGL(linear_mfma8_kernel, dim3((unsigned)blocks8), dim3(512), lin8_lds_bytes(), s, a);
+            if (big == 1) hipLaunchKernelGGL(linear_mfma8_kernel<2>, dim3((unsigned)blocks8), dim3(512), L8Geom<2>::LDS, s, a);
+            else          hipLaunchKernelGGL(linear_mfma8_kernel<1>, dim3((unsigned)blocks8), dim3(256), L8Geom<1>::LDS, s, a);
         } else
         if (nj == 4) hipLaunchKernelGGL(linear_mfma_kernel<4>, dim3((unsigned)blocks), dim3(256), lin_lds_bytes<4>(), s, a);
         else         hipLaunchKernelGGL(linear_mfma_kernel<2>, dim3((unsigned)blocks), dim3(256), lin_lds_bytes<2>(), s, a);

@@ -230,16 +230,17 @@ def test_big_tile_kernel_forced(engine, monkeypatch):
         for (wsgn, asgn) in [(1, 1), (0, 0), (1, 0)]:
             k += 1
             c = _random_case(rng, *shp, 8, wsgn, 8, asgn, w_pc=k % 2 == 0, a_pr=k % 3 != 0, zeros=k % 4 != 0, bias=k % 5 != 0)
-            monkeypatch.setenv("QE_LIN8", "1")
-            _capi.reload_env()
-            y8, path = _run(engine, c, True)
-            torch.cuda.synchronize()
             monkeypatch.setenv("QE_LIN8", "0")
             _capi.reload_env()
             y4, _ = _run(engine, c, True)
             torch.cuda.synchronize()
-            assert path == 1
-            _close(y8.cpu().numpy(), c["o64"], c["o32"], "big tile %s" % (shp,), c["fma"])
-            assert torch.equal(y8, y4), shp
+            for form in ("1", "2"):                  # 8 waves / 320-row tiles; 4 waves / 160-row tiles, one stage buffer
+                monkeypatch.setenv("QE_LIN8", form)
+                _capi.reload_env()
+                y8, path = _run(engine, c, True)
+                torch.cuda.synchronize()
+                assert path == 1
+                _close(y8.cpu().numpy(), c["o64"], c["o32"], "big tile %s form %s" % (shp, form), c["fma"])
+                assert torch.equal(y8, y4), (shp, form)
     monkeypatch.delenv("QE_LIN8")
     _capi.reload_env()
