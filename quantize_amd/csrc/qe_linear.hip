@@ -582,12 +582,8 @@ __global__ __launch_bounds__(256 * WMW, WMW == 2 ? 1 : 2) void linear_mfma8_kern
     if (tid < L8_TM) rowc[tid].z = (float)(part[tid] + part[L8_TM + tid] + part[2 * L8_TM + tid] + part[3 * L8_TM + tid]);
     if (tid < L8_TN) colc[tid].w = (float)(part[4 * L8_TM + tid] + (WMW == 2 ? part[4 * L8_TM + L8_TN + tid] : 0));
     __syncthreads();                                      // sums visible
-    const bool vec4 = (a.O & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
-    // Two patches per wave (the operand buffers are free now): tile t + 1 is converted while tile t's patch round trip is in
-    // flight.  A wave's own LDS operations complete in order, so its reads see its writes and a later tile's writes cannot
-    // overtake the reads of the tile before -- no lgkmcnt drain between them (the 64 x 64-deep form drains twice per tile).
-    float *patch0 = reinterpret_cast<float *>(lsm) + wave * (2 * 32 * 36);
-    const int rrow = lane >> 3, rq = lane & 7;
+    // A wave's own LDS operations complete in order, so its reads see its writes and a later tile's writes cannot overtake
+    // the reads of the tile before: no lgkmcnt drain between them.
     // symmetric operands (zx' = 0 for the wave's 160 rows, zw' = 0 for its 64 columns): out = bias + (sx sw) S_aw -- the three
     // correction terms of the general form are exact zeros there, so both forms give the same bits; no per-row constants read
     bool sym;
@@ -600,9 +596,13 @@ __global__ __launch_bounds__(256 * WMW, WMW == 2 ? 1 : 2) void linear_mfma8_kern
     }
     const float sx_all = a.x_scale[0];
     const bool fast = sym && a.x_per_tensor;
-    auto convert = [&](int i, int j, float (&v)[16]) __attribute__((always_inline)) {
+    // The epilogue is instantiated twice and the choice made ONCE: inside it there is no branch.  hipcc's wait-count pass
+    // starts every basic block that follows a branch with s_waitcnt vmcnt(0) while the kernel holds LDS-DMA instructions it
+    // cannot prove retired -- with a (wave-uniform) bounds test around every tile's stores that was a drain of ALL
+    // outstanding global stores in front of every tile: 21 k cycles of epilogue per wave whatever the store shape (stamps).
+    auto convert = [&](int i, int j, float (&v)[16], auto fast_tag) __attribute__((always_inline)) {
         const float4 cc = colc[wn * 64 + j * 32 + col];   // sw, zw', bias, S_w
-        if (fast) {
+        if constexpr (decltype(fast_tag)::value) {
             const float al = sx_all * cc.x;
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = fmaf(al, (float)acc[i][j][r], cc.z);
@@ -615,54 +615,39 @@ __global__ __launch_bounds__(256 * WMW, WMW == 2 ? 1 : 2) void linear_mfma8_kern
                 t = fmaf(rc.y, cc.w, t);
                 t = fmaf(rc.w, cc.y, t);
                 v[r] = fmaf(rc.x * cc.x, t, cc.z);
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // at most four rows' constants live (else 64 VGPRs of them: scratch)
             }
         }
     };
-    auto flush = [&](int i, int j, const float *patch) __attribute__((always_inline)) {
-        const int64_t row0 = m0 + wm * 160 + i * 32;
-        const int c4 = n0 + wn * 64 + j * 32 + 4 * rq;
-        if (row0 + 32 <= a.B && n0 + wn * 64 + j * 32 + 32 <= a.O) {   // wave-uniform: plain stores
+    // a patch is the wave's 32 rows x 64 columns of one row tile (both column tiles): read back as 4 rows x 256 contiguous
+    // bytes per store instruction (16 lanes per row)
+    float *patch0 = reinterpret_cast<float *>(lsm) + wave * (32 * 64);
+    const int r4 = lane >> 4, q16 = lane & 15;
+    const uint32_t voff = (uint32_t)r4 * (uint32_t)a.O + 4u * (uint32_t)q16;   // elements; r4 O + 64 < 2^31 (O < 2^29)
+    auto tiles = [&](auto fast_tag, auto full_tag) __attribute__((always_inline)) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int rt8 = 8 * k + rrow;
-                const float4 o4 = *reinterpret_cast<const float4 *>(patch + rt8 * 36 + 4 * rq);
-                *reinterpret_cast<float4 *>(a.out + (row0 + rt8) * a.O + c4) = o4;
+        for (int i = 0; i < 5; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float v[16];
+                convert(i, j, v, fast_tag);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) patch0[((r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + col] = v[r];
             }
-        } else {
+            const int64_t row0 = m0 + wm * 160 + i * 32;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int rt8 = 8 * k + rrow;
-                const float4 o4 = *reinterpret_cast<const float4 *>(patch + rt8 * 36 + 4 * rq);
-                const int64_t row = row0 + rt8;
-                if (row < a.B && c4 < a.O) *reinterpret_cast<float4 *>(a.out + row * a.O + c4) = o4;
+            for (int k = 0; k < 8; ++k) {
+                const float4 o4 = *reinterpret_cast<const float4 *>(patch0 + (4 * k + r4) * 64 + 4 * q16);
+                // wave-uniform base (scalar registers) + ONE per-lane 32-bit offset for all 40 stores of the wave
+                float *base = a.out + (row0 + 4 * k) * (int64_t)a.O + (n0 + wn * 64);
+                if constexpr (decltype(full_tag)::value) *reinterpret_cast<float4 *>(base + voff) = o4;
+                else if (row0 + 4 * k + r4 < a.B) *reinterpret_cast<float4 *>(base + voff) = o4;
             }
         }
     };
-    if (vec4) {
-#pragma unroll
-        for (int t = 0; t < 10; ++t) {
-            float v[16];
-            convert(t >> 1, t & 1, v);
-            if (t > 0) flush((t - 1) >> 1, (t - 1) & 1, patch0 + ((t - 1) & 1) * (32 * 36));
-            float *pw = patch0 + (t & 1) * (32 * 36);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) pw[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + col] = v[r];
-        }
-        flush(4, 1, patch0 + (32 * 36));
-    } else {
-#pragma unroll
-        for (int t = 0; t < 10; ++t) {
-            const int i = t >> 1, j = t & 1;
-            float v[16];
-            convert(i, j, v);
-            const int c = n0 + wn * 64 + j * 32 + col;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wm * 160 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < a.B && c < a.O) a.out[row * a.O + c] = v[r];
-            }
-        }
-    }
+    // O % 256 == 0 and `out` 16-byte aligned (host); only the LAST row tile can be ragged: it alone takes the form with a row test
+    if (m0 + L8_TM <= a.B) { if (fast) tiles(std::true_type{}, std::true_type{}); else tiles(std::false_type{}, std::true_type{}); }
+    else tiles(std::false_type{}, std::false_type{});
 #ifdef QE_STAMP
     LIN_ST(6);   // epilogue issue
     __builtin_amdgcn_s_waitcnt(0x0f70);
@@ -733,11 +718,12 @@ extern "C" int qe_quantlinear(const qe_qparam *x, const qe_qparam *w, const floa
         (void)raised;
         // 128-deep stages: 320 x 256 tiles (one 8-wave workgroup per CU) when the reduction is deep, 160 x 256 tiles (two 4-wave
         // workgroups per CU) when the layer is bound by its stores (K <= 1024) -- either when the problem fills the chip with
-        // them.  QE_LIN8=0: never, 1: the 8-wave form, 2: the 4-wave form (tuning / tests)
+        // them (O % 256 == 0: whole column tiles).  QE_LIN8=0: never, 1: the 8-wave form, 2: the 4-wave form
         int big = 0;
-        if ((K % L8_K) == 0 && B * (int64_t)K < (1ll << 32) && (int64_t)O * K < (1ll << 32)) {
-            if (K > 1024 && ((B + 319) / 320) * ((O + L8_TN - 1) / L8_TN) >= kNumCU) big = 1;
-            else if (K <= 1024 && ((B + 159) / 160) * ((O + L8_TN - 1) / L8_TN) >= 2 * kNumCU) big = 2;
+        if ((K % L8_K) == 0 && (O % L8_TN) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && B * (int64_t)K < (1ll << 32) &&
+            (int64_t)O * K < (1ll << 32) && O < (1 << 28)) {
+            if (K > 1024 && (B / 320) * (O / L8_TN) >= kNumCU) big = 1;
+            else if (K <= 1024 && (B / 160) * (O / L8_TN) >= 2 * kNumCU) big = 2;
             if (const char *e = env_get("QE_LIN8")) big = atoi(e);
             if (big < 0 || big > 2) big = 0;
         }
@@ -747,7 +733,7 @@ extern "C" int qe_quantlinear(const qe_qparam *x, const qe_qparam *w, const floa
                 hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_mfma8_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L8Geom<1>::LDS) == hipSuccess;
             (void)raised8;
             const int tm = big == 1 ? 320 : 160;
-            const int64_t blocks8 = ((B + tm - 1) / tm) * ((O + L8_TN - 1) / L8_TN);
+            const int64_t blocks8 = ((B + tm - 1) / tm) * (O / L8_TN);
             if (blocks8 > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
             if (big == 1) hipLaunchKernelGGL(linear_mfma8_kernel<2>, dim3((unsigned)blocks8), dim3(512), L8Geom<2>::LDS, s, a);
             else          hipLaunchKernelGGL(linear_mfma8_kernel<1>, dim3((unsigned)blocks8), dim3(256), L8Geom<1>::LDS, s, a);

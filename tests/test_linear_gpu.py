@@ -226,7 +226,7 @@ def test_big_tile_kernel_forced(engine, monkeypatch):
     from quantize_amd import capi as _capi
     rng = np.random.RandomState(11)
     k = 0
-    for shp in [(64, 768, 130), (129, 3072, 96), (200, 1024, 512), (700, 128, 520), (321, 256, 256), (1, 128, 4), (130, 64, 257)]:
+    for shp in [(330, 768, 256), (129, 3072, 256), (200, 1024, 512), (700, 128, 512), (321, 256, 256), (640, 3072, 256), (64, 768, 130), (1, 128, 4)]:
         for (wsgn, asgn) in [(1, 1), (0, 0), (1, 0)]:
             k += 1
             c = _random_case(rng, *shp, 8, wsgn, 8, asgn, w_pc=k % 2 == 0, a_pr=k % 3 != 0, zeros=k % 4 != 0, bias=k % 5 != 0)
