@@ -311,6 +311,15 @@ __device__ __forceinline__ void mfma_epilogue_impl(const MfmaArgs &a, v16i (&acc
                     emit(r, (r & 3) + 8 * (r >> 2), t, fmaf(al[r], (float)acc[t][r], bi[r]));
                 }
                 }
+            } else if (full_oc) {
+                // ragged column tile, whole channel strip: ONE exec region around the 16 stores.  With a test per store
+                // every store is a basic block of its own, and hipcc opens each block behind a branch with s_waitcnt
+                // vmcnt(0) in kernels that hold LDS-DMA instructions in a loop (sm2, ws): every store of the tile waited
+                // for the acknowledgement of the one before it.
+                if (valid[t]) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) emit(r, (r & 3) + 8 * (r >> 2), t, fmaf(al[r], (float)acc[t][r], bi[r]));
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -352,6 +361,16 @@ __device__ __forceinline__ void mfma_epilogue_impl(const MfmaArgs &a, v16i (&acc
                         float v = (float)acc[t][r] + ct[dr];
                         if (need_sx) v = fmaf(-zwc[r], (float)sxs[t], v);
                         emit(r, dr, t, fmaf(al[r], v, bi[r]));
+                    }
+                } else if (full_oc) {
+                    if (valid[t]) {                    // one exec region (see the symmetric form)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int dr = (r & 3) + 8 * (r >> 2);
+                            float v = (float)acc[t][r] + ct[dr];
+                            if (need_sx) v = fmaf(-zwc[r], (float)sxs[t], v);
+                            emit(r, dr, t, fmaf(al[r], v, bi[r]));
+                        }
                     }
                 } else {
 #pragma unroll

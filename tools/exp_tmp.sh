@@ -1,9 +1,8 @@
 set -o pipefail
-timeout -k 10 600 python -m pytest tests/test_linear_gpu.py -x -q > gpurun_out/r03x_lin_test.txt 2>&1; rc=$?; tail -15 gpurun_out/r03x_lin_test.txt; [ $rc -eq 0 ] || exit 1
-for v in 0 1 2 auto; do
-if [ $v = auto ]; then unset QE_LIN8; else export QE_LIN8=$v; fi
-timeout -k 10 200 python tools/bench_linear.py --steps 5 > gpurun_out/r03x_linear_$v.json; python -c "
-import json;j=json.load(open('gpurun_out/r03x_linear_$v.json'));print('QE_LIN8=$v', j['value'], j['ms_per_step'], j.get('per_shape') or j)"
+timeout -k 10 900 python -m pytest tests/test_conv_gpu.py tests/test_requant_gpu.py -x -q > gpurun_out/r03y_conv_tests.txt 2>&1; rc=$?; tail -5 gpurun_out/r03y_conv_tests.txt; [ $rc -eq 0 ] || exit 1
+for i in 1 2; do
+timeout -k 10 200 python bench.py --steps 200 --warmup 5 --no-cpu-baseline > gpurun_out/r03y_bench_$i.json 2> gpurun_out/r03y_bench_$i.err || exit 1
+python -c "
+import json;j=json.load(open('gpurun_out/r03y_bench_$i.json'));print('bench', j['value'], j['ms_per_step'], j['roofline']['conv_stack_ms'])"
 done
-export QE_LIN8=1
-QE_LIB=quantize_amd/_ext/libqe_hip_stamp.so timeout -k 10 120 python tools/stamp_linear.py 50432 768 768 50432 768 3072 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r03x_stamp_linear8c.txt
+timeout -k 10 300 python bench.py --steps 5 --warmup 2 --per-layer --cold --no-cpu-baseline > gpurun_out/r03y_pl.json 2> gpurun_out/r03y_pl.err; grep -E "^ *[0-9]+ (layer|conv)|sum of" gpurun_out/r03y_pl.err | awk '{print $1,$2,$3,$4,$5,$6,$7,$8,$10}' 
