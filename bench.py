@@ -70,6 +70,9 @@ def parse_args():
     ap.add_argument("--layer-streams", type=int, default=1,
                     help="DIAGNOSTIC: issue layer i on stream i %% S (the 53 problems are independent in this bench; a real network's "
                          "layers are not) -- bounds what co-scheduling kernels of different phases could buy")
+    ap.add_argument("--branch-streams", action="store_true",
+                    help="the downsample branch of a stage's first block on a second stream beside conv1..conv3 of that block "
+                         "(the concurrency a real, dependent ResNet-50 forward has); fork at the block's input, join at its end")
     ap.add_argument("--mb-stagger", type=int, default=0,
                     help="with --microbatches M: micro-batch m starts m*K layers behind micro-batch 0")
     ap.add_argument("--microbatches", type=int, default=1,
@@ -347,7 +350,31 @@ def main():
     if M > 1 and args.mb_stagger:
         stag_ev = [torch.cuda.Event() for _ in range(M)]
 
+    BR = args.branch_streams
+    if BR:
+        assert M == 1 and LS == 1 and not args.graph and not args.layers
+        br_stream = torch.cuda.Stream(device=dev)
+        br_sp = ctypes.c_void_p(br_stream.cuda_stream)
+        br_fork = [torch.cuda.Event() for _ in range(4)]
+        br_join = [torch.cuda.Event() for _ in range(4)]
+        names = [L.spec.name for L in layers]
+
     def step():
+        if BR:
+            k = 0
+            for i, L in enumerate(layers):
+                nm = names[i]
+                if nm.endswith(".0.conv1"):
+                    br_fork[k].record(stream)            # the block's input is ready
+                    br_stream.wait_event(br_fork[k])
+                    layers[names.index(nm[:-5] + "downsample")].run(br_sp)
+                    br_join[k].record(br_stream)
+                if nm.endswith(".downsample"):
+                    stream.wait_event(br_join[k])        # the block's end: residual add needs both branches
+                    k += 1
+                    continue
+                L.run(sp)
+            return
         if LS > 1:
             ls_fork.record(stream)
             for s_ in ls_streams:
@@ -413,6 +440,8 @@ def main():
     run_step = graph.replay if graph is not None else step
     if M > 1:
         launch_mode = launch_mode_mb + (", staggered by %d layers" % args.mb_stagger if args.mb_stagger else "")
+    if BR:
+        launch_mode = "eager C-ABI calls, the 4 downsample branches on a second stream beside conv1..3 of their block"
     if LS > 1:
         launch_mode = "DIAGNOSTIC: layer i on stream i %% %d (independent problems co-scheduled)" % LS
 

@@ -885,7 +885,7 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     a.PADW = p.ws ? p.PADW : sh->padding;
     a.dbg = g_mfma_dbg;
     a.rq_out = nullptr; a.rq_scale = nullptr; a.rq_zero = nullptr; a.rq_status = nullptr;
-    a.rq_qmin = a.rq_qmax = a.rq_lo = a.rq_hi = 0.0f; a.rq_offset = 0;
+    a.rq_qmin = a.rq_qmax = a.rq_lo = a.rq_hi = 0.0f; a.rq_offset = 0; a.rq_patch = 0;
     if (rq != nullptr) {
         if (rq->n_bits != 8 || rq->n_param != 1 || rq->out == nullptr) return QE_ERR_UNSUPPORTED;
         a.rq_out = rq->out; a.rq_scale = rq->scale; a.rq_zero = rq->zero;
@@ -940,11 +940,19 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     // LDS room for the epilogue's copy of the tile's S_w prefix rows (asymmetric activations; stage_ptab)
     size_t lds_e = p.lds;
     a.ptab_off = 0;
+    // lane = pixel kernels (halo, sm2, stem) with fused re-quantisation, one image per tile: the codes leave through a
+    // workgroup byte patch at the START of the dynamic LDS (<= 32 KB: MT x pixel slots; the staging image is dead by then)
+    // instead of as byte stores of 32-byte runs; the epilogue's tables sit behind it.  QE_RQ_PATCH=0: byte stores.
+    const bool rq_patch = rq != nullptr && !p.flat && !p.flatg && !p.ws && !p.sm2d && p.GI == 1 && (p.OH * p.OW) % 4 == 0 &&
+                          (p.TH * p.OW) % 4 == 0 && (reinterpret_cast<uintptr_t>(rq->out) & 3) == 0 &&
+                          !(env_get("QE_RQ_PATCH") && atoi(env_get("QE_RQ_PATCH")) == 0);
+    const size_t stage_bytes = rq_patch ? std::max(p.lds, (size_t)32 * 1024) : p.lds;
+    if (rq_patch) { a.rq_patch = 1; lds_e = stage_bytes; }
     if (p.sm2d) {
         a.ptab_off = sm2d_ptab_off(p.GI, p.IHT, p.IWP, sh->W, p.sm2d);   // the natural-order buffers are free once the K loop is done
     } else if (!p.flat && !p.flatg) {
         const size_t tab = (size_t)p.MT * (sh->KH + 1) * (sh->KW + 1) * sizeof(int);
-        const size_t off = align_up(p.lds, 16);
+        const size_t off = align_up(stage_bytes, 16);
         if (off + tab <= (size_t)(p.sm2 ? MF_MAX_LDS_SM2 : MF_MAX_LDS)) { a.ptab_off = (int)off; lds_e = off + tab; }
     }
     // border classes: rows r < n_top have their top taps clipped, the last n_bot rows their bottom taps (columns alike).

@@ -5,7 +5,9 @@ namespace qe {
 
 #define QE_SMALLIC(WM, WN, NIW)                                                                                          \
     do {                                                                                                                \
-        if (a.rq_out != nullptr)                                                                                        \
+        if (a.rq_out != nullptr && a.rq_patch && (NIW) == 7)                                                            \
+            hipLaunchKernelGGL((conv_mfma_smallic_kernel<WM, WN, NIW, true, (NIW) == 7>), dim3(blocks), dim3(MF_THREADS), lds, s, a);  \
+        else if (a.rq_out != nullptr)                                                                                   \
             hipLaunchKernelGGL((conv_mfma_smallic_kernel<WM, WN, NIW, true>), dim3(blocks), dim3(MF_THREADS), lds, s, a);  \
         else                                                                                                            \
             hipLaunchKernelGGL((conv_mfma_smallic_kernel<WM, WN, NIW, false>), dim3(blocks), dim3(MF_THREADS), lds, s, a); \

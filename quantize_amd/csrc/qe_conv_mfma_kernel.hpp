@@ -49,6 +49,8 @@ struct MfmaArgs {
     float rq_qmin, rq_qmax, rq_lo, rq_hi;   // clamp of the quantiser; representable range of the code (tpack's range test)
     unsigned rq_offset;                     // stored code = (q + offset) & 0xff (tpack.cu:108-111)
     int32_t *rq_status;                     // bit 0 set when a value fails the range test (NaN, or qmin/qmax outside the code range)
+    int rq_patch;                           // lane = pixel kernels (halo, sm2, stem), one image per tile: the tile's codes go through a
+                                            // workgroup byte patch [MT][32 NIW WN] at the start of the dynamic LDS and leave as 16-byte row pieces
 };
 
 // y -> stored 8-bit code with the arithmetic of the fused quantise+pack kernel (qe_tpack.hip tp_quantize + tp_code):
@@ -228,7 +230,7 @@ struct TileGeom {
     int NT;      // valid columns (images that exist x OHWt)
 };
 
-template <int WM, int WN, int NIW, bool RQ>
+template <int WM, int WN, int NIW, bool RQ, bool PATCH = false>
 __device__ __forceinline__ void mfma_epilogue_impl(const MfmaArgs &a, v16i (&acc)[NIW], const int (&sxs)[NIW],
                                                    const bool need_sx, const TileGeom g, const int ot,
                                                    const int wm, const int wn, const int col, const int h, const int KK,
@@ -272,8 +274,21 @@ __device__ __forceinline__ void mfma_epilogue_impl(const MfmaArgs &a, v16i (&acc
     // consecutive bytes of row dr, lanes 32-63 of row dr + 4).  Two wider forms were built and measured slower: a per-wave
     // LDS patch read back as 16-byte pieces (hipcc spilled 600-900 B per lane) and a 4 x 4 byte transpose across lane quads
     // by DPP + v_perm with dword stores (4.63 against 4.41 ms for the fused stack; 264 B of scratch in the 7-slot kernels).
+    // PATCH (RQ only): byte (row wm 32 + 4 h + dr, pixel slot q) of the workgroup's patch; slots past the tile and rows past OC
+    // hold garbage that rq_patch_copy_out never reads, so no store below needs a test -- and the epilogue no branch
+    extern __shared__ __attribute__((aligned(16))) uint8_t qe_ep_smem[];
+    constexpr int PSTR = 32 * NIW * WN;
+    uint8_t *prow = qe_ep_smem + (wm * 32 + 4 * h) * PSTR + wn * 32 + col;
+    auto put = [&](int dr, int t, unsigned code) __attribute__((always_inline)) {
+        if constexpr (PATCH) prow[dr * PSTR + t * (WN * 32)] = (uint8_t)code;
+        else (out_q + (int64_t)dr * OHW)[voff[t]] = (uint8_t)code;
+    };
     auto emit = [&](int r, int dr, int t, float val) __attribute__((always_inline)) {
-        if constexpr (RQ) (out_q + (int64_t)dr * OHW)[voff[t]] = (uint8_t)(unsigned)rq_value(rqc, val, bad);
+        if constexpr (RQ && PATCH) {
+            bool b = false;                                // slots past the tile / rows past OC must not raise the range flag
+            put(dr, t, (unsigned)rq_value(rqc, val, b));
+            bad |= b && valid[t] && (full_oc || oc_base + dr < a.OC);
+        } else if constexpr (RQ) put(dr, t, (unsigned)rq_value(rqc, val, bad));
         else (out_w + (int64_t)dr * OHW)[voff[t]] = val;
     };
 
@@ -294,7 +309,7 @@ __device__ __forceinline__ void mfma_epilogue_impl(const MfmaArgs &a, v16i (&acc
 #pragma unroll
         for (int t = 0; t < NIW; ++t) {
             const int q0 = (wn + t * WN) * 32;
-            if (full_oc && q0 + 32 <= g.NT) {
+            if (PATCH || (full_oc && q0 + 32 <= g.NT)) {
                 if (RQ && fast) {
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
@@ -302,8 +317,8 @@ __device__ __forceinline__ void mfma_epilogue_impl(const MfmaArgs &a, v16i (&acc
                         const v2f y = __builtin_elementwise_fma(v2f{al[r], al[r + 1]}, v2f{(float)acc[t][r], (float)acc[t][r + 1]},
                                                                 v2f{bi[r], bi[r + 1]});
                         const v2f c2 = rq_fast2(rqc, y);
-                        (out_q + (int64_t)dr * OHW)[voff[t]] = (uint8_t)(unsigned)c2.x;
-                        (out_q + (int64_t)(dr + 1) * OHW)[voff[t]] = (uint8_t)(unsigned)c2.y;
+                        put(dr, t, (unsigned)c2.x);
+                        put(dr + 1, t, (unsigned)c2.y);
                     }
                 } else {
 #pragma unroll
@@ -311,7 +326,7 @@ __device__ __forceinline__ void mfma_epilogue_impl(const MfmaArgs &a, v16i (&acc
                     emit(r, (r & 3) + 8 * (r >> 2), t, fmaf(al[r], (float)acc[t][r], bi[r]));
                 }
                 }
-            } else if (full_oc) {
+            } else if (!RQ && full_oc) {       // (fp32 stores only: in the re-quantising instances this form spilled 576 B per lane)
                 // ragged column tile, whole channel strip: ONE exec region around the 16 stores.  With a test per store
                 // every store is a basic block of its own, and hipcc opens each block behind a branch with s_waitcnt
                 // vmcnt(0) in kernels that hold LDS-DMA instructions in a loop (sm2, ws): every store of the tile waited
@@ -354,7 +369,7 @@ __device__ __forceinline__ void mfma_epilogue_impl(const MfmaArgs &a, v16i (&acc
                 const int cid = c < a.n_lft ? 1 + c : (c >= a.OW - a.n_rgt ? 1 + a.n_lft + (a.OW - 1 - c) : 0);
                 const float *ct = crow + (rid * ncc + cid) * MT;
                 const int q0 = (wn + t * WN) * 32;
-                if (full_oc && q0 + 32 <= g.NT) {      // wave-uniform: plain stores, no per-element exec masks
+                if (PATCH || (full_oc && q0 + 32 <= g.NT)) {      // wave-uniform: plain stores, no per-element exec masks
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int dr = (r & 3) + 8 * (r >> 2);
@@ -362,7 +377,7 @@ __device__ __forceinline__ void mfma_epilogue_impl(const MfmaArgs &a, v16i (&acc
                         if (need_sx) v = fmaf(-zwc[r], (float)sxs[t], v);
                         emit(r, dr, t, fmaf(al[r], v, bi[r]));
                     }
-                } else if (full_oc) {
+                } else if (!RQ && full_oc) {
                     if (valid[t]) {                    // one exec region (see the symmetric form)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
@@ -427,24 +442,56 @@ __device__ __forceinline__ void mfma_epilogue_impl(const MfmaArgs &a, v16i (&acc
                     v = fmaf(fn * zxp, zw[r], v);
                 }
                 const float res = fmaf(al[r], v, bi[r]);
-                if (valid[t] && oc < a.OC) emit(r, dr, t, res);
+                if (PATCH || (valid[t] && oc < a.OC)) emit(r, dr, t, res);
             }
         }
     }
     if constexpr (RQ) rq_report(a, bad);
 }
 
+// The patch of the PATCH form -> global memory: [MT][PSTR] codes, row = output channel ot MT + row, slot = pixel of the tile
+// (one image per tile: a channel's NT pixels are contiguous from row oh0).  16-byte pieces at dword alignment (host: OH OW, TH OW
+// multiples of 4); called by every thread of the workgroup after its waves' epilogues.
+template <int MT, int PSTR, int THREADS>
+__device__ __forceinline__ void rq_patch_copy_out(const MfmaArgs &a, const TileGeom &g, const int ot, const int tid)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t qe_ep_smem[];
+    __syncthreads();
+    constexpr int PPR = PSTR / 16;
+    const int OHW = a.OH * a.OW;
+    const int NT = g.NT;
+    for (int e = tid; e < MT * PPR; e += THREADS) {
+        const int row = e / PPR, px = 16 * (e - row * PPR);
+        const int oc = ot * MT + row;
+        if (oc < a.OC && px < NT) {
+            const uint4 d4 = *reinterpret_cast<const uint4 *>(qe_ep_smem + row * PSTR + px);
+            uint8_t *dst = a.rq_out + ((int64_t)g.n0 * a.OC + oc) * OHW + (int64_t)g.oh0 * a.OW + px;
+            if (px + 16 <= NT) {
+                __builtin_memcpy(dst, &d4, 16);
+            } else {                                                       // NT % 4 == 0: whole dwords
+                const uint32_t dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (px + 4 * k < NT) __builtin_memcpy(dst + 4 * k, &dd[k], 4);
+            }
+        }
+    }
+}
+
 // RQ is a template parameter of the KERNELS that share this epilogue (own instantiations for the fused re-quantisation:
 // as a run-time branch inside one kernel its extra live state pushed the 7-column-tile kernels past 256 VGPRs -- scratch in
 // kernels the fp32 path launches).
-template <int WM, int WN, int NIW, bool RQ = false>
+// PATCH is a template parameter of the KERNELS too (own instantiations, chosen by the launchers from a.rq_patch): as a run-time
+// branch between two copies of the epilogue it cost the 7-column-tile kernels 32-576 bytes of scratch and the fused stack
+// went 3.5 -> 6.2 ms.
+template <int WM, int WN, int NIW, bool RQ = false, bool PATCH = false>
 __device__ __forceinline__ void mfma_epilogue(const MfmaArgs &a, v16i (&acc)[NIW], const int (&sxs)[NIW],
                                               const bool need_sx, const TileGeom g, const int ot,
                                               const int wm, const int wn, const int col, const int h, const int KK,
                                               const int *ptab = nullptr,   // LDS copy of this tile's rows of a.ws, or null
                                               const float *ctab = nullptr) // LDS [border class][MT] correction table, or null
 {
-    mfma_epilogue_impl<WM, WN, NIW, RQ>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab, ctab);
+    mfma_epilogue_impl<WM, WN, NIW, RQ, RQ && PATCH>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab, ctab);
 }
 
 // Asymmetric activations (zx' != 0): the border-aware S_w lookups of the epilogue go to an LDS copy of this tile's MT
@@ -528,7 +575,7 @@ __device__ __forceinline__ bool decode_tile(const MfmaArgs &a, int &pt, int &ot,
 // activations; NS = 32-channel chunks per stage: the 256 threads split into NS groups that each
 // fetch one chunk of the stage, so one HBM round trip feeds NS*KK MFMA steps per column tile.
 // ---------------------------------------------------------------------------------------------
-template <int WM, int WN, int NIW, int KKT, bool X8, int NS, bool RQ = false>
+template <int WM, int WN, int NIW, int KKT, bool X8, int NS, bool RQ = false, bool PATCH = false>
 __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -769,7 +816,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs
     {
         const float *ctab = stage_ctab<32 * WM>(a, smem, ot, tid, MF_THREADS);
         const int *ptab = ctab ? nullptr : stage_ptab<32 * WM>(a, smem, ot, tid, MF_THREADS);
-        mfma_epilogue<WM, WN, NIW, RQ>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab, ctab);
+        if constexpr (RQ && PATCH) __syncthreads();   // every wave is done with the staging image and the pixel sums: the patch takes their place
+        mfma_epilogue<WM, WN, NIW, RQ, PATCH>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab, ctab);
+        if constexpr (RQ && PATCH) rq_patch_copy_out<32 * WM, 32 * NIW * WN, MF_THREADS>(a, g, ot, tid);
     }
 #ifdef QE_STAMP
     QE_ST(7);       // epilogue stores issued
@@ -800,7 +849,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_kernel(const MfmaArgs
 // it made hipcc spill 700-900 VGPRs (two live copies of the accumulators).
 // Tile geometry, LDS halo image, staging threads and epilogue are the halo kernel's.
 // ---------------------------------------------------------------------------------------------
-template <int WMS, int KKT, int SPLIT, bool RQ = false>
+template <int WMS, int KKT, int SPLIT, bool RQ = false, bool PATCH = false>
 __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_sm2_kernel(const MfmaArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1043,8 +1092,10 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_sm2_kernel(const Mfma
     QE_ST(6);
     const float *ctab = stage_ctab<MT>(a, smem, ot, tid, MF_THREADS);
     const int *ptab = ctab ? nullptr : stage_ptab<MT>(a, smem, ot, tid, MF_THREADS);
-    mfma_epilogue<2 * WMS, WN, NTC, RQ>(a, acc0, sxs, need_sx, g, ot, 2 * wms, wn, col, h, KK, ptab, ctab);
-    mfma_epilogue<2 * WMS, WN, NTC, RQ>(a, acc1, sxs, need_sx, g, ot, 2 * wms + 1, wn, col, h, KK, ptab, ctab);
+    if constexpr (RQ && PATCH) __syncthreads();
+    mfma_epilogue<2 * WMS, WN, NTC, RQ, PATCH>(a, acc0, sxs, need_sx, g, ot, 2 * wms, wn, col, h, KK, ptab, ctab);
+    mfma_epilogue<2 * WMS, WN, NTC, RQ, PATCH>(a, acc1, sxs, need_sx, g, ot, 2 * wms + 1, wn, col, h, KK, ptab, ctab);
+    if constexpr (RQ && PATCH) rq_patch_copy_out<MT, 32 * NTC * WN, MF_THREADS>(a, g, ot, tid);
 #ifdef QE_STAMP
     QE_ST(7);
     if (a.dbg != nullptr && lane == 0) {
@@ -1370,7 +1421,7 @@ __global__ __launch_bounds__(2 * MF_THREADS, 2) void conv_mfma_ws_kernel(const M
 // 4 consecutive pixels starting at column ow*stride + 4h of row oh*stride + kh.
 //   Wt layout here: [KH][2][OCP][16], byte (kw - 4h)*4 + ic.
 // ---------------------------------------------------------------------------------------------
-template <int WM, int WN, int NIW, bool RQ = false>
+template <int WM, int WN, int NIW, bool RQ = false, bool PATCH = false>
 __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_smallic_kernel(const MfmaArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1505,7 +1556,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void conv_mfma_smallic_kernel(const 
     {
         const float *ctab = stage_ctab<32 * WM>(a, reinterpret_cast<uint8_t *>(smem), ot, tid, MF_THREADS);
         const int *ptab = ctab ? nullptr : stage_ptab<32 * WM>(a, reinterpret_cast<uint8_t *>(smem), ot, tid, MF_THREADS);
-        mfma_epilogue<WM, WN, NIW, RQ>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab, ctab);
+        if constexpr (RQ && PATCH) __syncthreads();
+        mfma_epilogue<WM, WN, NIW, RQ, PATCH>(a, acc, sxs, need_sx, g, ot, wm, wn, col, h, KK, ptab, ctab);
+        if constexpr (RQ && PATCH) rq_patch_copy_out<32 * WM, 32 * NIW * WN, MF_THREADS>(a, g, ot, tid);
     }
 }
 
@@ -2237,7 +2290,9 @@ void launch_mfma_flat_x4(const MfmaArgs &a, int niw, int ns, unsigned blocks, si
 
 #define QE_MFMA_K(WM, WN, NIW, KKT, X8, NS)                                                                                     \
     do {                                                                                                                        \
-        if (a.rq_out != nullptr)                                                                                                \
+        if (a.rq_out != nullptr && a.rq_patch && (WM) == 4 && (NIW) == 7 && (KKT) == 9 && (X8) && (NS) == 1)                    \
+            hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, NIW, KKT, X8, NS, true, (WM) == 4 && (NIW) == 7 && (KKT) == 9 && (X8) && (NS) == 1>), dim3(blocks), dim3(MF_THREADS), lds, s, a); \
+        else if (a.rq_out != nullptr)                                                                                           \
             hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, NIW, KKT, X8, NS, true>), dim3(blocks), dim3(MF_THREADS), lds, s, a);  \
         else                                                                                                                    \
             hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, NIW, KKT, X8, NS, false>), dim3(blocks), dim3(MF_THREADS), lds, s, a); \
