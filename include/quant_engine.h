@@ -259,6 +259,11 @@ int qe_quantlinear_float_input(const float *x, const qe_qparam *w, const float *
 /* 0 = order-preserving fp32 kernel, 1 = int8 MFMA GEMM (8-bit x 8-bit operands, K % 64 == 0, 16-byte aligned streams). */
 int qe_quantlinear_path(const qe_qparam *x, const qe_qparam *w, int64_t B, int32_t K, int32_t O);
 
+/* quantlinear_float_input: 0 = order-preserving fp32 kernel (bit-identical to the reference's fused chain), 1 = bf16 MFMA
+ * GEMM on an exact three-way split of the activations (8-bit weights, K % 32 == 0, 16-byte aligned operands; results within
+ * fp32 accumulation rounding of the exact sum; QE_LIN_F32_MFMA=0 disables it). */
+int qe_quantlinear_float_input_path(const float *x, const qe_qparam *w, int64_t B, int32_t K, int32_t O);
+
 /* ---- auxiliary (no counterpart in the reference's extension) ---------------------------------
  * Global average pool of an fp32 NCHW tensor: out[plane] = mean(x[plane][0..P)) for n_planes = N*C planes of P
  * contiguous floats.  The reference's models do this in PyTorch (torchvision ResNet: AdaptiveAvgPool2d); bench.py's

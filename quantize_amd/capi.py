@@ -19,7 +19,7 @@ DTYPES = {"uint8": 0, "int8": 1, "int16": 2, "int32": 3, "int64": 4,
 SYMBOLS = ["qe_error_string", "qe_last_hip_error", "qe_version", "qe_target_arch", "qe_packed_nbytes",
            "qe_tpack", "qe_tunpack", "qe_quantconv2d_workspace_bytes", "qe_quantconv2d",
            "qe_quantconv2d_float_input", "qe_quantconv2d_path", "qe_quantlinear", "qe_quantlinear_float_input",
-           "qe_quantlinear_path", "qe_global_avgpool", "qe_conv_prepared_bytes", "qe_quantconv2d_prepared_workspace_bytes",
+           "qe_quantlinear_path", "qe_quantlinear_float_input_path", "qe_global_avgpool", "qe_conv_prepared_bytes", "qe_quantconv2d_prepared_workspace_bytes",
            "qe_conv_prepare", "qe_quantconv2d_prepared", "qe_quantize_pack", "qe_quantconv2d_float_input_workspace_bytes",
            "qe_quantconv2d_float_input_ws", "qe_conv_f32_prepare", "qe_quantconv2d_float_input_prepared",
            "qe_quantconv2d_float_input_path", "qe_quantconv2d_requant_path", "qe_quantconv2d_requant_workspace_bytes",
@@ -80,6 +80,8 @@ def lib():
     L.qe_quantlinear_float_input.argtypes = [vp, ctypes.POINTER(QeQParam), vp, i64, i32, i32, vp, vp]
     L.qe_quantlinear_path.restype = i32
     L.qe_quantlinear_path.argtypes = [ctypes.POINTER(QeQParam), ctypes.POINTER(QeQParam), i64, i32, i32]
+    L.qe_quantlinear_float_input_path.restype = i32
+    L.qe_quantlinear_float_input_path.argtypes = [vp, ctypes.POINTER(QeQParam), i64, i32, i32]
     L.qe_global_avgpool.restype = i32
     L.qe_global_avgpool.argtypes = [vp, i64, i32, vp, vp]
     L.qe_conv_prepared_bytes.restype = sz
@@ -338,6 +340,10 @@ def quantlinear(xq, wq, bias, B, K, O, out=None, stream=None):
     check(lib().qe_quantlinear(ctypes.byref(xq), ctypes.byref(wq), None if bias is None else bias.data_ptr(),
                                int(B), int(K), int(O), out.data_ptr(), _stream(stream)))
     return out
+
+
+def linear_float_input_path(x, wq, B, K, O):
+    return int(lib().qe_quantlinear_float_input_path(x.data_ptr(), ctypes.byref(wq), int(B), int(K), int(O)))
 
 
 def quantlinear_float_input(x, wq, bias, O, out=None, stream=None):

@@ -661,6 +661,171 @@ __global__ __launch_bounds__(256 * WMW, WMW == 2 ? 1 : 2) void linear_mfma8_kern
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// quantlinear_float_input on the matrix cores (round 3): fp32 activations x 8-bit weight codes, K % 32 == 0.
+//   out[b,o] = bias[o] + sw[o] ( S_xq[b,o] - zw[o] S_x[b] ),   S_xq = sum_k x q_w,   S_x = sum_k x
+// S_xq runs on v_mfma_f32_32x32x16_bf16 with the EXACT three-way split of the activations the float-input convolution
+// uses (qe_conv_f32.hip): x = x1 + x2 + x3, each part's significand <= 8 bits (bf16), every product with an integer code
+// |q| <= 255 (bf16-exact) exact in fp32; only the fp32 accumulation rounds.  (A non-finite x gives NaN in the remainder
+// terms where the reference's chain keeps +-inf: declared divergence, as for the convolution.)
+// Workgroup = 2 x 2 waves, tile 128 x 128, wave 64 x 64 = 2 x 2 MFMA tiles x 3 splits; stage = 32 k: the thread that
+// fetched 4 consecutive k of a row splits them and writes 3 x 8 bytes; weights: 16 codes -> 16 bf16 per thread.
+// LDS images [row][32 k] bf16 (64-byte rows), 16-byte pieces XOR-swizzled as in linear_mfma_kernel.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 v8bf_l __attribute__((ext_vector_type(8)));
+typedef float v16f_l __attribute__((ext_vector_type(16)));
+constexpr int LF_T = 128, LF_K = 32;
+constexpr int LF_PLANE = LF_T * LF_K * 2;                 // bytes of one [128][32] bf16 image (8 KB)
+constexpr size_t linf_lds_bytes() { return (size_t)4 * LF_PLANE + LF_T * sizeof(float) + 2 * LF_T * sizeof(float4); }
+
+__global__ __launch_bounds__(256, 2) void linear_f32_mfma_kernel(const LinArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lsm[];   // 3 activation split images, 1 weight image, row sums, column constants
+    float *rowsum = reinterpret_cast<float *>(lsm + 4 * LF_PLANE);
+    float4 *colc = reinterpret_cast<float4 *>(rowsum + LF_T);        // sw, zw, bias, 0
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int col = lane & 31, h = lane >> 5;
+    const int n_ct = (a.O + LF_T - 1) / LF_T;
+    const int64_t bid = blockIdx.x;
+    const int ct = (int)(bid % n_ct);
+    const int64_t m0 = (bid / n_ct) * LF_T;
+    const int n0 = ct * LF_T;
+
+    if (tid < LF_T) {
+        const int cc = (n0 + tid < a.O) ? n0 + tid : a.O - 1;
+        colc[tid] = make_float4(a.w_per_tensor ? a.w_scale[0] : a.w_scale[cc], a.w_per_tensor ? a.w_zero[0] : a.w_zero[cc],
+                                a.bias ? a.bias[cc] : 0.0f, 0.0f);
+    }
+
+    // activations: thread <-> (row r = (tid >> 3) + 32 i, k quad q = tid & 7): one float4 per pass i
+    const int q8 = tid & 7;
+    const float *xrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (tid >> 3) + 32 * i;
+        const int64_t row = (m0 + r < a.B) ? m0 + r : a.B - 1;
+        xrow[i] = a.xf + row * a.K + 4 * q8;
+    }
+    // weights: thread <-> (column c = tid >> 1, 16-code half hh = tid & 1)
+    const int wc = tid >> 1, whh = tid & 1;
+    const uint8_t *wrow = a.w + (int64_t)((n0 + wc < a.O) ? n0 + wc : a.O - 1) * a.K + 16 * whh;
+    const float wshift = a.w_sign ? 128.0f : 0.0f;       // stored u -> q = u - 128 (signed) | u
+
+    float4 xv[4];
+    uint4 wv;
+    auto fetch = [&](int st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const float4 *>(xrow[i] + st * LF_K);
+        wv = *reinterpret_cast<const uint4 *>(wrow + st * LF_K);
+    };
+    float sx[4] = {0.0f, 0.0f, 0.0f, 0.0f};              // this thread's share of S_x of its four rows
+    auto stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (tid >> 3) + 32 * i;
+            float x[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
+            sx[i] += (x[0] + x[1]) + (x[2] + x[3]);
+            // piece (16 bytes = 8 k) q8 >> 1 of the row, its half q8 & 1
+            uint8_t *dst = lsm + r * 64 + 16 * ((q8 >> 1) ^ ((r >> 2) & 3)) + 8 * (q8 & 1);
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) {
+                uint32_t u[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    u[j] = __float_as_uint(x[j]) & 0xffff0000u;           // sp == 2: the remainder has <= 8 significant bits
+                    x[j] -= __uint_as_float(u[j]);
+                }
+                *reinterpret_cast<uint2 *>(dst + sp * LF_PLANE) =
+                    make_uint2(__builtin_amdgcn_perm(u[1], u[0], 0x07060302u), __builtin_amdgcn_perm(u[3], u[2], 0x07060302u));
+            }
+        }
+        // 16 codes -> 16 bf16 (two 16-byte pieces: k 16 hh .. 16 hh + 7, + 8 .. + 15)
+        const uint32_t ww[4] = {wv.x, wv.y, wv.z, wv.w};
+        uint32_t pk[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t b0 = (ww[j >> 1] >> (16 * (j & 1))) & 0xffu, b1 = (ww[j >> 1] >> (16 * (j & 1) + 8)) & 0xffu;
+            const float f0 = (float)b0 - wshift, f1 = (float)b1 - wshift;   // |q| <= 255: exact in bf16
+            pk[j] = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
+        }
+        uint8_t *wd = lsm + 3 * LF_PLANE + wc * 64;
+        const int sw3 = (wc >> 2) & 3;
+        *reinterpret_cast<uint4 *>(wd + 16 * ((2 * whh) ^ sw3)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        *reinterpret_cast<uint4 *>(wd + 16 * ((2 * whh + 1) ^ sw3)) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+    };
+
+    v16f_l acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int n_stages = a.K / LF_K;
+    const int swz = (col >> 2) & 3;
+    const int a_off = (wm * 64 + col) * 64, b_off = 3 * LF_PLANE + (wn * 64 + col) * 64;
+    fetch(0);
+    for (int st = 0; st < n_stages; ++st) {
+        stage();
+        __syncthreads();
+        if (st + 1 < n_stages) fetch(st + 1);             // in flight under the MFMAs
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int po = 16 * ((2 * ks + h) ^ swz);
+            v8bf_l fb[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const v8bf_l *>(lsm + b_off + j * 32 * 64 + po);
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const v8bf_l fa = *reinterpret_cast<const v8bf_l *>(lsm + sp * LF_PLANE + a_off + i * 32 * 64 + po);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // S_x: the 8 threads of a row (consecutive lanes) add their shares
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = sx[i];
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+        if (q8 == 0) rowsum[(tid >> 3) + 32 * i] = v;
+    }
+    __syncthreads();
+    // D: batch row on the register, feature on the lane
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int cl = wn * 64 + j * 32 + col;
+        const int c = n0 + cl;
+        const float4 cc = colc[cl];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int64_t row = m0 + rl;
+                const float v = fmaf(cc.x, fmaf(-cc.y, rowsum[rl], acc[i][j][r]), cc.z);
+                if (row < a.B && c < a.O) a.out[row * a.O + c] = v;
+            }
+        }
+    }
+}
+
+static bool linf_mfma_eligible(const float *x, const qe_qparam *w, int64_t B, int K, int O)
+{
+    if (const char *e = env_get("QE_LIN_F32_MFMA")) { if (atoi(e) == 0) return false; }
+    return w->n_bits == 8 && (K % LF_K) == 0 && K >= LF_K && B > 0 && O > 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(w->data) & 15) == 0;
+}
+
 static int check_lin_q(const qe_qparam *q, int64_t n_expected)
 {
     if (q == nullptr || q->data == nullptr || q->scale == nullptr || q->zero == nullptr) return QE_ERR_ARG;
@@ -764,10 +929,26 @@ extern "C" int qe_quantlinear_float_input(const float *x, const qe_qparam *w, co
     a.x_bits = 0; a.x_sign = 0; a.x_per_tensor = 1;
     a.w_bits = w->n_bits; a.w_sign = w->sign; a.w_per_tensor = w->n_param == 1;
     a.B = B; a.K = K; a.O = O; a.out = out; a.dbg = nullptr;
+    if (linf_mfma_eligible(x, w, B, K, O)) {
+        const int64_t blocks_m = ((B + LF_T - 1) / LF_T) * ((O + LF_T - 1) / LF_T);
+        if (blocks_m > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
+        static const bool raised_f = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_f32_mfma_kernel),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)linf_lds_bytes()) == hipSuccess;
+        (void)raised_f;
+        hipLaunchKernelGGL(linear_f32_mfma_kernel, dim3((unsigned)blocks_m), dim3(256), linf_lds_bytes(), static_cast<hipStream_t>(stream), a);
+        QE_LAUNCH_CHECK();
+        return QE_OK;
+    }
     const int64_t blocks = ((B + 31) / 32) * ((O + 31) / 32);
     if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(linear_generic_kernel<true>, dim3((unsigned)blocks), dim3(256), 0,
                        static_cast<hipStream_t>(stream), a);
     QE_LAUNCH_CHECK();
     return QE_OK;
+}
+
+extern "C" int qe_quantlinear_float_input_path(const float *x, const qe_qparam *w, int64_t B, int32_t K, int32_t O)
+{
+    if (w == nullptr) return 0;
+    return qe::linf_mfma_eligible(x, w, B, K, O) ? 1 : 0;
 }

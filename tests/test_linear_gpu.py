@@ -32,6 +32,7 @@ def _close(got, exact64, chain32, what, fma=None):
 
 def test_g5_golden_cases(engine, g5):
     paths = set()
+    fpaths = set()
     for key in g5.index:
         B, K, O, wb, wsgn, ab, asgn = [int(v) for v in g5.get(key, "meta")]
         w = (_t(g5.get(key, "w_packed")), _t(g5.get(key, "w_des")), _t(g5.get(key, "w_scale")), _t(g5.get(key, "w_zero")))
@@ -39,9 +40,14 @@ def test_g5_golden_cases(engine, g5):
         bias = None if bias is None else _t(bias)
         x = g5.get(key, "x")
         if x is not None:
-            y = engine.quantlinear_float_input(_t(x), *w, bias)
-            # the fp32 kernel keeps the reference's k-sequential fmaf chain: bit-identical to the oracle's
-            assert np.array_equal(y.cpu().numpy(), g5.get(key, "chain32_fma")), key
+            xt = _t(x)
+            y = engine.quantlinear_float_input(xt, *w, bias)
+            fpath = capi.linear_float_input_path(xt, capi.qparam(w[0], wb, wsgn, w[2], w[3]), B, K, O)
+            fpaths.add(fpath)
+            # the fp32 kernel keeps the reference's k-sequential fmaf chain: bit-identical to the oracle's (the bf16 x 3
+            # MFMA kernel -- 8-bit weights, K % 32 == 0 -- is held to the tolerance below)
+            if fpath == 0:
+                assert np.array_equal(y.cpu().numpy(), g5.get(key, "chain32_fma")), key
         else:
             xs, xz = _t(g5.get(key, "x_scale")), _t(g5.get(key, "x_zero"))
             y = engine.quantlinear(_t(g5.get(key, "x_packed")), _t(g5.get(key, "x_des")), xs, xz, *w, bias)
@@ -113,9 +119,12 @@ def _run(engine, c, via_capi):
     bias = None if c["bias"] is None else _t(c["bias"])
     wp, sw, zw = _t(c["wp"]), _t(c["sw"]), _t(c["zw"])
     if "x" in c:
+        xt = _t(c["x"])
+        wq = capi.qparam(wp, c["wb"], c["wsgn"], sw, zw)
+        fpath = 2 * capi.linear_float_input_path(xt, wq, c["B"], c["K"], c["O"])     # 0: fp32 chain kernel, 2: bf16 x 3 MFMA kernel
         if via_capi:
-            return capi.quantlinear_float_input(_t(c["x"]), capi.qparam(wp, c["wb"], c["wsgn"], sw, zw), bias, c["O"]), 0
-        return engine.quantlinear_float_input(_t(c["x"]), wp, _t(c["wd"]), sw, zw, bias), 0
+            return capi.quantlinear_float_input(xt, wq, bias, c["O"]), fpath
+        return engine.quantlinear_float_input(xt, wp, _t(c["wd"]), sw, zw, bias), fpath
     xp, sx, zx = _t(c["xp"]), _t(c["sx"]), _t(c["zx"])
     xq, wq = capi.qparam(xp, c["ab"], c["asgn"], sx, zx), capi.qparam(wp, c["wb"], c["wsgn"], sw, zw)
     path = capi.linear_path(xq, wq, c["B"], c["K"], c["O"])
@@ -131,7 +140,8 @@ SWEEP = [(1, 16, 1), (5, 48, 300), (130, 64, 257), (257, 80, 33), (64, 768, 130)
 @pytest.mark.parametrize("via_capi", [False, True])
 def test_random_sweep_vs_oracle(engine, via_capi):
     rng = np.random.RandomState(5)
-    quant = [(8, 1, 8, 1), (8, 0, 8, 0), (8, 1, 8, 0), (4, 1, 4, 1), (3, 1, 5, 0), (8, 1, 0, 0), (4, 0, 0, 0)]
+    quant = [(8, 1, 8, 1), (8, 0, 8, 0), (8, 1, 8, 0), (4, 1, 4, 1), (3, 1, 5, 0), (8, 1, 0, 0), (4, 0, 0, 0), (8, 0, 0, 0)]
+    seen_f32_mfma = []
     k = 0
     for shp in SWEEP:
         for (wb, wsgn, ab, asgn) in quant:
@@ -144,8 +154,31 @@ def test_random_sweep_vs_oracle(engine, via_capi):
             _close(got, c["o64"], c["o32"], "shape %s quant %s" % (shp, (wb, wsgn, ab, asgn)), c["fma"])
             if path == 0:
                 assert np.array_equal(got, c["fma"]), "fp32 kernel not bit-exact: %s %s" % (shp, (wb, wsgn, ab, asgn))
+            elif path == 2:
+                assert wb == 8 and ab == 0 and shp[1] % 32 == 0
+                seen_f32_mfma.append(shp)
             else:
                 assert wb == 8 and ab == 8 and shp[1] % 16 == 0
+    assert len(seen_f32_mfma) >= 6      # quantlinear_float_input ran on the matrix cores for the 8-bit-weight, K % 32 == 0 shapes
+
+
+def test_float_input_mfma_vit_shapes(engine, monkeypatch):
+    """quantlinear_float_input on the bf16 x 3 MFMA kernel at ViT-B/16 shapes (the 'float route' of a packed Linear): absolute
+    1e-5 against the float64-exact value at the headline scales, ragged rows / columns, asymmetric weights; and the same
+    problem on the fp32 chain kernel (QE_LIN_F32_MFMA=0) stays bit-identical to the oracle's fused chain."""
+    rng = np.random.RandomState(23)
+    for (B, K, O, zeros) in [(197, 768, 768, False), (130, 768, 3072, True), (70, 3072, 768, False), (256, 768, 1000, True), (1, 32, 1, True)]:
+        c = _random_case(rng, B, K, O, 8, 1, 0, 0, w_pc=True, a_pr=False, zeros=zeros, bias=True)
+        y, path = _run(engine, c, True)
+        assert path == 2
+        err = np.abs(y.cpu().numpy().astype(np.float64) - c["o64"]).max()
+        assert err <= max(1e-5, 2.0 * np.abs(c["o32"].astype(np.float64) - c["o64"]).max()), (B, K, O, err)
+    monkeypatch.setenv("QE_LIN_F32_MFMA", "0")
+    capi.reload_env()
+    y0, path0 = _run(engine, c, True)
+    assert path0 == 0 and np.array_equal(y0.cpu().numpy(), c["fma"])
+    monkeypatch.delenv("QE_LIN_F32_MFMA")
+    capi.reload_env()
 
 
 def test_vit_shapes_and_row_independence(engine):
