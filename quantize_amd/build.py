@@ -20,7 +20,7 @@ EXT_DIR = os.path.join(_HERE, "_ext")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 HIP_SOURCES = ["qe_api.hip", "qe_tpack.hip", "qe_conv_generic.hip", "qe_conv_mfma.hip",
-               "qe_conv_mfma_i0.hip", "qe_conv_mfma_i1.hip", "qe_conv_mfma_i2.hip", "qe_conv_mfma_i3.hip", "qe_conv_mfma_i4.hip", "qe_conv_mfma_i5.hip", "qe_conv_mfma_i6.hip", "qe_conv_mfma_i7.hip", "qe_conv_mfma_i8.hip", "qe_linear.hip", "qe_conv_flatd.hip", "qe_conv_f32.hip", "qe_conv_halod.hip", "qe_conv_pwr.hip", "qe_conv_c3.hip"]
+               "qe_conv_mfma_i0.hip", "qe_conv_mfma_i1.hip", "qe_conv_mfma_i2.hip", "qe_conv_mfma_i3.hip", "qe_conv_mfma_i4.hip", "qe_conv_mfma_i5.hip", "qe_conv_mfma_i6.hip", "qe_conv_mfma_i7.hip", "qe_conv_mfma_i8.hip", "qe_linear.hip", "qe_conv_flatd.hip", "qe_conv_f32.hip", "qe_conv_pwr.hip"]
 HIP_HEADERS = ["qe_common.h", "qe_conv_mfma_kernel.hpp", os.path.join(INCLUDE, "quant_engine.h")]
 ARCH = "gfx950"
 

@@ -180,10 +180,6 @@ __global__ __launch_bounds__(64) void conv_mfma_prep_smallic_kernel(const PrepAr
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-bool sm2d_plan(const qe_conv_shape *sh, int waves, int *GI, int *TH, int *niw, size_t *lds);                    // qe_conv_halod.hip
-int sm2d_ptab_off(int GI, int IHT, int IWP, int W, int waves);
-void launch_mfma_sm2d(const MfmaArgs &a, int niw, int waves, unsigned blocks, size_t lds, hipStream_t s);
-constexpr int QE_SM2D_DEFAULT = 0;
 
 struct MfmaPlan {
     bool ok = false;
@@ -193,7 +189,6 @@ struct MfmaPlan {
     bool smallic = false;
     int GI = 1, NS = 1;
     bool flat = false, wraw = false, ws = false, s2 = false, sm2 = false;
-    int sm2d = 0;              // 3x3 / stride 1: both operands by LDS-DMA (qe_conv_halod.hip); value = waves per workgroup (4 | 8)
     bool expand = false;       // sub-8-bit activations are expanded to 8-bit codes in the workspace first
     bool x4 = false;           // 4-bit activations read from the packed stream by the flat kernel itself
     size_t xe_off = 0;
@@ -320,23 +315,8 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits, bool
     // QE_SM2 0 1): 56x56 64->64 0.083 -> 0.068 ms, 14x14 256->256 0.050 -> 0.048, 28x28 +4 %, 7x7 maps and the
     // stride-2 layers +15 % (the warp-specialised kernel / bigger halo tiles win there).  Default: stride 1 and a
     // tile that is either 64 channels wide or a whole image; QE_SM2=1 forces it wherever it fits, QE_SM2=0 never.
-    // 3x3 / stride 1 / pad 1, 8-bit activations, > 64 output channels, IC % 32 == 0: the LDS-DMA kernel (qe_conv_halod.hip).
-    // QE_SM2D=0 keeps the register-staged kernels below.
-    const int sm2d_env = env_get("QE_SM2D") ? atoi(env_get("QE_SM2D")) : QE_SM2D_DEFAULT;   // 1: 8 waves, 2: 4 waves
-    if (!p.flat && !p.flatg && !p.smallic && p.KK == 9 && x_bits == 8 && p.cfg == 0 && sm2d_env != 0) {
-        int GI, TH, niw;
-        size_t lds;
-        const int waves = sm2d_env == 1 ? 8 : 4;
-        if (sm2d_plan(sh, waves, &GI, &TH, &niw, &lds)) {
-            p.sm2d = waves; p.GI = GI; p.TH = TH; p.IHT = TH + 2; p.IWP = p.OW + 2; p.lds = lds; p.NS = 1;
-            p.NCH = sh->IC / 32; p.NG = 2 * p.NCH;
-            p.ni = (GI * TH * p.OW + 31) / 32; p.niw = niw;
-            p.wt_bytes = (size_t)p.KK * p.NG * p.OCP * 16;
-            if ((int64_t)p.wt_bytes >= (1ll << 31)) { p.sm2d = 0; p.GI = 1; p.TH = 0; }
-        }
-    }
     const int sm2_env = env_get("QE_SM2") ? atoi(env_get("QE_SM2")) : -1;
-    if (!p.sm2d && !p.flat && !p.flatg && !p.smallic && p.KK == 9 && sh->KW == 3 && sh->KH == 3 && x_bits == 8 && p.cfg <= 1 && sm2_env != 0) {
+    if (!p.flat && !p.flatg && !p.smallic && p.KK == 9 && sh->KW == 3 && sh->KH == 3 && x_bits == 8 && p.cfg <= 1 && sm2_env != 0) {
         const int max_px = 32 * (p.cfg == 0 ? 8 : 16);
         int GI = 1;
         if (p.OH * p.OW <= max_px / 2) GI = std::max(1, std::min((int)sh->N, max_px / (p.OH * p.OW)));
@@ -366,7 +346,7 @@ static MfmaPlan make_plan8(const qe_conv_shape *sh, int x_bits, int w_bits, bool
             if (!p.sm2) { p.GI = 1; p.TH = 0; p.NS = 1; }   // the halo plan below starts from scratch
         }
     }
-    if (p.flat || p.flatg || p.sm2 || p.sm2d) {
+    if (p.flat || p.flatg || p.sm2) {
     } else if (p.smallic) {
         // stem layout: K = (kh) x [kw 0..7][ic 0..3]; the whole (tiny) channel depth is one stage
         p.NCH = 1;
@@ -675,8 +655,6 @@ int launch_flatd(const qe_qparam *x, const qe_qparam *w, const float *bias, cons
 bool pwr_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w, const RequantHost *rq);  // qe_conv_pwr.hip
 int launch_pwr(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh, float *out, hipStream_t s,
                const RequantHost *rq);
-bool c3_eligible(const MfmaArgs &a);                                                                          // qe_conv_c3.hip
-int launch_c3(const MfmaArgs &a, int64_t n_units, hipStream_t s);
 constexpr int QE_FLATD_DEFAULT = 4;   // 7x7 planes only: -17..-20 % there; the wide variants tie or lose to the register-staged kernels (profiles/r02b_ab_flatd.txt)
 
 bool mfma_conv_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w)
@@ -696,7 +674,7 @@ bool mfma_conv_requant_fused(const qe_conv_shape *sh, const qe_qparam *x, const 
 {
     if (x->n_param != 1 || rq_bits != 8 || rq_n_param != 1) return false;
     const MfmaPlan p = make_plan(sh, x->n_bits, w->n_bits);
-    if (!p.ok || p.sm2d) return false;
+    if (!p.ok) return false;
     if (p.flat || p.flatg) {
         const qe_conv_shape ds = p.sub ? dense_shape(sh) : *sh;
         const size_t patch = p.flatg ? (size_t)p.GI * p.MT * ds.H * ds.W : (size_t)p.MT * 32 * p.ni;
@@ -943,14 +921,12 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
     // lane = pixel kernels (halo, sm2, stem) with fused re-quantisation, one image per tile: the codes leave through a
     // workgroup byte patch at the START of the dynamic LDS (<= 32 KB: MT x pixel slots; the staging image is dead by then)
     // instead of as byte stores of 32-byte runs; the epilogue's tables sit behind it.  QE_RQ_PATCH=0: byte stores.
-    const bool rq_patch = rq != nullptr && !p.flat && !p.flatg && !p.ws && !p.sm2d && p.GI == 1 && (p.OH * p.OW) % 4 == 0 &&
+    const bool rq_patch = rq != nullptr && !p.flat && !p.flatg && !p.ws && p.GI == 1 && (p.OH * p.OW) % 4 == 0 &&
                           (p.TH * p.OW) % 4 == 0 && (reinterpret_cast<uintptr_t>(rq->out) & 3) == 0 &&
                           !(env_get("QE_RQ_PATCH") && atoi(env_get("QE_RQ_PATCH")) == 0);
     const size_t stage_bytes = rq_patch ? std::max(p.lds, (size_t)32 * 1024) : p.lds;
     if (rq_patch) { a.rq_patch = 1; lds_e = stage_bytes; }
-    if (p.sm2d) {
-        a.ptab_off = sm2d_ptab_off(p.GI, p.IHT, p.IWP, sh->W, p.sm2d);   // the natural-order buffers are free once the K loop is done
-    } else if (!p.flat && !p.flatg) {
+    if (!p.flat && !p.flatg) {
         const size_t tab = (size_t)p.MT * (sh->KH + 1) * (sh->KW + 1) * sizeof(int);
         const size_t off = align_up(stage_bytes, 16);
         if (off + tab <= (size_t)(p.sm2 ? MF_MAX_LDS_SM2 : MF_MAX_LDS)) { a.ptab_off = (int)off; lds_e = off + tab; }
@@ -1002,13 +978,6 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
         QE_LAUNCH_CHECK();
         return QE_OK;
     }
-    if (p.sm2d) {
-        if (rq != nullptr) return QE_ERR_UNSUPPORTED;     // the opt-in LDS-DMA 3x3 kernel has no re-quantising instances
-        launch_mfma_sm2d(a, p.niw, p.sm2d, (unsigned)blocks, p.lds, s);
-        QE_LAUNCH_CHECK();
-        return QE_OK;
-    }
-    if (p.sm2 && rq == nullptr && c3_eligible(a)) return launch_c3(a, n_units, s);   // whole-image kernel (qe_conv_c3.hip)
     if (p.sm2) {
         const int units = p.GI * p.IHT * ((sh->W + 3) / 4);
         const int split = units <= 64 ? 4 : (units <= 128 ? 2 : 1);   // channel slices of the staging threads

@@ -282,7 +282,7 @@ def test_conv_error_messages(engine):
 
 @pytest.mark.parametrize("env", [{"QE_SM2": "0", "QE_WS": "1"}, {"QE_SM2": "0", "QE_WS": "1", "QE_WS_NOPAD": "1"},
                                  {"QE_SM2": "0", "QE_WS": "0"}, {"QE_SM2": "1"}, {"QE_FLAT_NIW": "4"}, {"QE_FLAT_NIW": "5"},
-                                 {"QE_FLAT_NIW": "7"}, {"QE_CHUNK_IMAGES": "0"}, {"QE_CHUNK_IMAGES": "1"}, {"QE_SUBSAMPLE": "0"}, {"QE_SUBSAMPLE": "1"}, {"QE_FLATG": "0"}, {"QE_CTAB": "0"}, {"QE_SM2D": "1"}, {"QE_SM2D": "2"}, {"QE_SM2D": "0"}])
+                                 {"QE_FLAT_NIW": "7"}, {"QE_CHUNK_IMAGES": "0"}, {"QE_CHUNK_IMAGES": "1"}, {"QE_SUBSAMPLE": "0"}, {"QE_SUBSAMPLE": "1"}, {"QE_FLATG": "0"}, {"QE_CTAB": "0"}])
 def test_kernel_variants_forced_by_env(engine, env):
     """The tuning knobs select other kernel variants (two-strip / warp-specialised (padded, unpadded LDS rows) /
     single-role 3x3, flat tile widths, block maps); every variant must meet the same parity bar."""
