@@ -1,1 +1,4 @@
-timeout -k 10 300 python tools/bench_linear_f32.py 2>/dev/null | tee gpurun_out/r03z_bench_linear_f32.json
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout -k 10 1000 python -m pytest tests -m gpu -q -x > gpurun_out/r03zz_gputest.txt 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r03zz_gputest.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
+timeout -k 10 300 python bench.py > gpurun_out/r03zz_bench.json 2> gpurun_out/r03zz_bench.err; tail -c 700 gpurun_out/r03zz_bench.json
