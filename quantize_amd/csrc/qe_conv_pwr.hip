@@ -483,281 +483,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_pwr_kernel(const PwrArgs a
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------
-// Persistent form for shallow layers (IC = 64 | 128: the tile is 14 / 28 KB, two of them fit): ONE 8-wave workgroup per
-// CU walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ...  A layer with many tiles per CU (64 -> 256 @56x56: 14) pays
-// a tile's fetch -- one memory round trip, queued behind the CU's own stores -- before the tile's first store; with
-// two resident workgroups that start together (equal work: they stay in phase) the CU's store stream pauses for every
-// such fetch.  Here tile i + 1 is requested by LDS-DMA into the other buffer BEFORE the last strip of tile i is stored
-// and has that strip's 4 NRB stores' worth of time to land; the weights of a wave with one strip per tile never leave
-// its registers.  One raw s_barrier per tile; the activation recode (u ^ 0x80) moves to the fragments (2-4 k-steps).
-// Every DMA is inline asm (section 5.7 of the guide: M0 written in the statement that uses it): a DMA hipcc knows about
-// puts vmcnt(0) in front of every LDS store that follows -- here the epilogue's patch writes.
-// ---------------------------------------------------------------------------------------------
-template <int NT, int KS, int TW> struct PwrpGeom {
-    static constexpr int WAVES = 8;
-    using B = PwrGeom<NT, 8, KS, TW>;
-    static constexpr int NBUF = 3;                           // tile i in use, i + 1 landed, i + 2 in flight
-    static constexpr int TABOFF = NBUF * B::XBYTES;
-    static constexpr int PATCHOFF = TABOFF + B::TAB;
-    static constexpr int LDS = PATCHOFF + 8 * B::PATCH;
-};
-
-template <int NT, int KS, int TW>
-__global__ __launch_bounds__(512, 2) void conv_pwrp_kernel(const PwrArgs a)
-{
-    using G = PwrGeom<NT, 8, KS, TW>;
-    using GP = PwrpGeom<NT, KS, TW>;
-    constexpr int WAVES = 8;
-    constexpr int RS = G::RS, PXW = G::PXW, NRB = G::NRB;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int col = lane & 31, h = lane >> 5;
-    const int P = a.P;
-    const int n_tiles = a.n_pix_tiles;
-    int pt = blockIdx.x;
-    if (pt >= n_tiles) return;
-
-    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
-    float *tab = reinterpret_cast<float *>(smem + GP::TABOFF) + wave * 128;
-    float *patch = reinterpret_cast<float *>(smem + GP::PATCHOFF) + wave * (8 * TW);
-
-    const int n_strips = a.OC >> 5;
-    const int n_my = (n_strips - wave + WAVES - 1) / WAVES;  // >= 1 (host: OC >= 256)
-
-    v4i wf[KS];
-    float c_sw, c_zw, c_bi;
-    auto load_w = [&](int strip) __attribute__((always_inline)) {
-        const int oc = strip * 32 + col;
-        const float *psw = a.w_scale + (a.w_per_tensor ? 0 : oc);
-        const float *pzw = a.w_zero + (a.w_per_tensor ? 0 : oc);
-        const float *pbi = a.bias ? a.bias + oc : psw;
-        const uint8_t *wl = a.w + (int64_t)oc * G::IC + 16 * h;
-        asm volatile("global_load_dword %0, %3, off\n\tglobal_load_dword %1, %4, off\n\tglobal_load_dword %2, %5, off"
-                     : "=&v"(c_sw), "=&v"(c_zw), "=&v"(c_bi) : "v"(psw), "v"(pzw), "v"(pbi) : "memory");
-#define QE_PWR_LW(K, OFF) if constexpr (KS > K) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(wf[K]) : "v"(wl) : "memory")
-        QE_PWR_LW(0, 0); QE_PWR_LW(1, 32); QE_PWR_LW(2, 64); QE_PWR_LW(3, 96);
-#undef QE_PWR_LW
-    };
-#define QE_PWRP_WAIT(N)                                                                                                   \
-    do {                                                                                                                  \
-        if constexpr (KS == 2) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(c_sw), "+v"(c_zw), "+v"(c_bi), "+v"(wf[0]), "+v"(wf[1]) : "i"(N) : "memory"); \
-        else asm volatile("s_waitcnt vmcnt(%7)" : "+v"(c_sw), "+v"(c_zw), "+v"(c_bi), "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[KS - 2]), "+v"(wf[KS - 1]) : "i"(N) : "memory"); \
-    } while (0)
-
-    // ---- tile pieces by LDS-DMA (asm): slot e = 64 * (wave + 8 i) + lane <-> (channel c, 16-byte piece j) ----
-    const int64_t x_total = (int64_t)a.N * G::IC * P;
-    const int64_t x_last16 = x_total - 16;
-    const uint32_t tail_word = *reinterpret_cast<const uint32_t *>(a.x + x_total - 4);
-    // EVERY wave issues PXW pieces per tile (a wave whose last piece does not exist fetches an earlier one again: same bytes to
-    // the same slot), so that the number of vector-memory operations between two points of the loop is a constant
-    int sl_c[PXW], sl_j[PXW], sl_q[PXW];
-#pragma unroll
-    for (int i = 0; i < PXW; ++i) {
-        sl_q[i] = (wave + WAVES * i) % G::XINSTR;
-        const int e = 64 * sl_q[i] + lane;
-        sl_c[i] = e / (RS / 16);
-        sl_j[i] = e - sl_c[i] * (RS / 16);
-    }
-    // returns the piece index this lane has to patch by hand once the tile has landed (-1: none)
-    auto issue_x = [&](int tile, int buf) __attribute__((always_inline)) -> int {
-        const int n0 = tile / a.tiles_per_image;
-        const int p0 = (tile - n0 * a.tiles_per_image) * TW;
-        int fix = -1;
-#pragma unroll
-        for (int i = 0; i < PXW; ++i) {
-            {
-                int64_t src = ((int64_t)n0 * G::IC + sl_c[i]) * P + p0 + 16 * sl_j[i];
-                bool skip = false;
-                if (src > x_last16) {
-                    if (src < x_total) { skip = true; fix = i; }
-                    else src = x_last16;
-                }
-                const uint64_t live = __builtin_amdgcn_ballot_w64(!skip);
-                const uint8_t *gsrc = a.x + (skip ? x_last16 : src);
-                const uint32_t dst = __builtin_amdgcn_readfirstlane(smem_lds + (uint32_t)(buf * G::XBYTES + 1024 * sl_q[i]));
-                unsigned keep;
-                unsigned long long ex;
-                // `live` is a ballot (a subset of EXEC); s_mov, not s_and: nothing here may write SCC, hipcc keeps a compare
-                // alive across the statement
-                asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                             "global_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0\n\ts_mov_b64 exec, %1"
-                             : "=&s"(keep), "=&s"(ex) : "v"(gsrc), "s"(dst), "s"(live) : "memory");
-            }
-        }
-        return fix;
-    };
-    auto patch_x = [&](int fix, int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < PXW; ++i)
-            if (i == fix) *reinterpret_cast<uint32_t *>(smem + buf * G::XBYTES + 1024 * sl_q[i] + 16 * lane) = tail_word;
-    };
-
-    int fix = issue_x(pt, 0);                                 // (only the last tile of the tensor ever needs the patch)
-    int fix_next = pt + (int)gridDim.x < n_tiles ? issue_x(pt + (int)gridDim.x, 1) : -1;
-    load_w(wave);
-
-    uint32_t rb_off[NRB];
-#pragma unroll
-    for (int k = 0; k < NRB; ++k) {
-        const int f = 64 * k + lane;
-        const int row = f / G::PPR, pc = f - row * G::PPR;
-        rb_off[k] = f < 8 * G::PPR ? (uint32_t)row * (uint32_t)P + 4u * (uint32_t)pc : 0u;
-    }
-    const float zxp = a.x_zero[0] - (a.x_sign ? 0.0f : 128.0f);
-    const float sx = a.x_scale[0];
-    const float zw_shift = a.w_sign ? 0.0f : 128.0f;
-    QE_PWRP_WAIT(0);
-    if (!a.bias) c_bi = 0.0f;
-    patch_x(fix, 0);
-    patch_x(fix_next, 1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    const int i16 = lane & 15;
-    const int tr_off = (16 * h + (i16 >> 1)) * RS + 16 * ((lane >> 4) & 1) + 8 * (i16 & 1);
-
-    float sxv[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) sxv[t] = 0.0f;
-    v16i acc[NT];
-    int swacc;
-    auto mma_strip = [&](auto sx_tag, int buf) __attribute__((always_inline)) {
-        constexpr bool SX = decltype(sx_tag)::value;
-        const uint8_t *tr_base = smem + buf * G::XBYTES + tr_off;
-        int sxacc[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            sxacc[t] = 0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0;
-        }
-        swacc = 0;
-#pragma unroll
-        for (int k = 0; k < KS; ++k) {
-            v4i wk = wf[k];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                wk[j] ^= (int)0x80808080;
-                swacc = __builtin_amdgcn_sdot4(wk[j], 0x01010101, swacc, false);
-            }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const uint8_t *src = tr_base + (k * 32) * RS + t * 32;
-                const v2i lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(src));
-                const v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3))) *)(src + 8 * RS));
-                v4i xf = {lo[0], lo[1], hi[0], hi[1]};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) xf[j] ^= (int)0x80808080;   // u - 128: signed q, or unsigned q - 128
-                if constexpr (SX) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) sxacc[t] = __builtin_amdgcn_sdot4(xf[j], 0x01010101, sxacc[t], false);
-                }
-                acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wk, xf, acc[t], 0, 0, 0);
-            }
-        }
-        if constexpr (SX) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) sxv[t] = (float)(sxacc[t] + __shfl_xor(sxacc[t], 32));
-        }
-    };
-    auto epilogue = [&](int tile, int strip, float e_sw, float e_zw, float e_bi, bool need_sx) __attribute__((always_inline)) {
-        const int n0 = tile / a.tiles_per_image;
-        const int p0 = (tile - n0 * a.tiles_per_image) * TW;
-        const int oc0 = strip * 32;
-        {
-            const float zwp = e_zw - zw_shift;
-            const int sw_sum = swacc + __shfl_xor(swacc, 32);
-            const float cst = fmaf((float)G::IC * zxp, zwp, -zxp * (float)sw_sum);
-            if (h == 0) {
-                tab[col] = sx * e_sw;
-                tab[32 + col] = cst;
-                tab[64 + col] = e_bi;
-                tab[96 + col] = zwp;
-            }
-        }
-        float *out_s = a.out + ((int64_t)n0 * a.OC + oc0) * P + p0;
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const float4 al = *reinterpret_cast<const float4 *>(tab + 8 * gq + 4 * h);
-            const float4 cs = *reinterpret_cast<const float4 *>(tab + 32 + 8 * gq + 4 * h);
-            const float4 bi = *reinterpret_cast<const float4 *>(tab + 64 + 8 * gq + 4 * h);
-            const float alv[4] = {al.x, al.y, al.z, al.w}, csv[4] = {cs.x, cs.y, cs.z, cs.w};
-            const float biv[4] = {bi.x, bi.y, bi.z, bi.w};
-            float zwv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (need_sx) {
-                const float4 zw = *reinterpret_cast<const float4 *>(tab + 96 + 8 * gq + 4 * h);
-                zwv[0] = zw.x; zwv[1] = zw.y; zwv[2] = zw.z; zwv[3] = zw.w;
-            }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int px = 32 * t + col;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    // the flat kernels' operation order exactly (their fused re-quantising epilogue must give the codes
-                    // of quantize_pack on THIS kernel's fp32 output bit for bit: tests/test_requant_gpu.py)
-                    float f = (float)acc[t][4 * gq + j] + csv[j];
-                    if (need_sx) f = fmaf(-zwv[j], sxv[t], f);
-                    v[j] = fmaf(alv[j], f, biv[j]);
-                }
-                if (32 * t + 32 <= TW || px < TW) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) patch[(4 * h + j) * TW + px] = v[j];
-                }
-            }
-            float *out_g = out_s + (int64_t)(8 * gq) * P;
-#pragma unroll
-            for (int k = 0; k < NRB; ++k) {
-                const float4 o4 = *reinterpret_cast<const float4 *>(patch + 4 * (64 * k + lane));
-                if (64 * k + 64 <= 8 * G::PPR || 64 * k + lane < 8 * G::PPR) *reinterpret_cast<float4 *>(out_g + rb_off[k]) = o4;
-            }
-        }
-    };
-
-    // Tile i is multiplied from buffer cur; tile i + 1 landed a tile ago; tile i + 2 is requested before the last strip's
-    // stores of tile i and has a whole tile's time to arrive -- a request joins the CU's memory pipe BEHIND the stores its
-    // eight waves have queued (~200 KB, ~10 us at the HBM rate), so one strip's worth of cover (the first version) stalled
-    // every tile switch.  The wait after the last strip leaves those PXW requests + the strip's stores outstanding.
-    int cur = 0;
-    for (;;) {
-        const int nxt = pt + (int)gridDim.x, nxt2 = nxt + (int)gridDim.x;
-        const bool has_next = nxt < n_tiles;
-        int fix_next2 = -1;
-        for (int s = 0; s < n_my; ++s) {
-            const bool sx_cur = __builtin_amdgcn_ballot_w64((c_zw - zw_shift) != 0.0f) != 0ull;   // this strip has asymmetric weights
-            if (sx_cur) mma_strip(std::true_type{}, cur); else mma_strip(std::false_type{}, cur);
-            const float e_sw = c_sw, e_zw = c_zw, e_bi = c_bi;
-            const bool last = s + 1 == n_my;
-            // next strip's weights FIRST (the counted wait below must cover them), then -- on the last strip -- the pieces of
-            // tile i + 2 (or, past the end, of this tile again: a constant count), then this strip's stores
-            if (n_my > 1) load_w(wave + (last ? 0 : s + 1) * WAVES);
-            if (last) {
-                const int f2 = issue_x(nxt2 < n_tiles ? nxt2 : pt, cur == 0 ? 2 : cur - 1);
-                fix_next2 = nxt2 < n_tiles ? f2 : -1;
-                epilogue(pt, wave + s * WAVES, e_sw, e_zw, e_bi, sx_cur);
-                QE_PWRP_WAIT(4 * NRB + PXW);
-            } else {
-                epilogue(pt, wave + s * WAVES, e_sw, e_zw, e_bi, sx_cur);
-                QE_PWRP_WAIT(4 * NRB);
-            }
-            if (!a.bias) c_bi = 0.0f;
-        }
-        if (!has_next) break;
-        patch_x(fix_next, cur == 2 ? 0 : cur + 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();     // tile i + 1 is complete for every wave; nobody reads tile i any more
-        asm volatile("" ::: "memory");
-        cur = cur == 2 ? 0 : cur + 1;
-        pt = nxt;
-        fix_next = fix_next2;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the surplus requests of the last tiles must not outlive the workgroup's LDS
-#undef QE_PWRP_WAIT
-}
+// (A persistent form -- one 8-wave workgroup per CU walking the tiles, the next tile requested by LDS-DMA one or two tiles ahead
+// into a second / third buffer -- was built, held to the parity bar and measured 10-23 % SLOWER than one tile per workgroup
+// (profiles/r03d_ab_persist.txt, r03t_ab_persist2.txt): the second resident workgroup of the plain form already overlaps more
+// than the prefetch buys.  Removed; git history at eb1114b.)
 
 // ---------------------------------------------------------------------------------------------
 // 7x7 planes (P = 49: the last stage of a bottleneck network, 512 -> 2048 @7x7).  Same scheme on the small-plane layout of
@@ -998,7 +727,7 @@ extern unsigned long long *g_mfma_dbg;   // qe_conv_mfma.hip (diagnostic builds)
 
 struct PwrPlan {
     int tw = 0, waves = 0, ks = 0, groups = 1;
-    bool persistent = false, s2 = false;
+    bool s2 = false;
 };
 
 // QE_PWR=0 disables the kernel, QE_PWR_GROUPS overrides the channel split (tuning).
@@ -1036,8 +765,6 @@ static bool pwr_plan(const qe_conv_shape *sh, const qe_qparam *x, const qe_qpara
     const int strips = sh->OC / 32;
     if (const char *e = env_get("QE_PWR_GROUPS")) { const int v = atoi(e); if (v >= 1 && strips % v == 0) groups = v; }
     pl->tw = tw; pl->waves = waves; pl->ks = ks; pl->groups = groups; pl->s2 = s2;
-    // IC <= 128 with at least one strip for each of 8 waves: the persistent double-buffered form (opt-in, QE_PWR_PERSIST=1)
-    pl->persistent = !s2 && ks <= 4 && sh->OC >= 256 && groups == 1 && (env_get("QE_PWR_PERSIST") && atoi(env_get("QE_PWR_PERSIST")) == 1);   // opt-in: +10-23 % against one tile per workgroup, also with the tile requested two tiles ahead (profiles/r03d_ab_persist.txt, r03t_ab_persist2.txt)
     return true;
 }
 
@@ -1063,7 +790,7 @@ static int pwr7_plan(const qe_conv_shape *sh, const qe_qparam *x, const qe_qpara
 }
 
 // rq != nullptr: the fused re-quantising form (8-bit codes, one scale: what the kernels' epilogue covers); the 7x7 and the
-// persistent kernels have none
+// kernel has none
 bool pwr_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w, const RequantHost *rq)
 {
     PwrPlan pl;
@@ -1071,7 +798,7 @@ bool pwr_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *
     if (rq != nullptr) {
         if (rq->n_bits != 8 || rq->n_param != 1 || rq->out == nullptr || (reinterpret_cast<uintptr_t>(rq->out) & 15) != 0) return false;
         if (env_get("QE_PWR_RQ") && atoi(env_get("QE_PWR_RQ")) == 0) return false;
-        return pwr_plan(sh, x, w, &pl) && !pl.persistent;
+        return pwr_plan(sh, x, w, &pl);
     }
     return pwr_plan(sh, x, w, &pl) || pwr7_plan(sh, x, w, &g) != 0;
 }
@@ -1147,24 +874,6 @@ int launch_pwr(const qe_qparam *x, const qe_qparam *w, const float *bias, const 
     const int64_t runs = ((int64_t)a.n_pix_tiles + a.chunk - 1) / a.chunk;
     const int64_t blocks = (runs + 7) / 8 * a.chunk * 8 * a.n_groups;
     if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
-    if (pl.persistent && rq == nullptr) {
-        int grid = kNumCU;
-        if (const char *e = env_get("QE_PWR_GRID")) { const int v = atoi(e); if (v >= 1) grid = v; }
-        if (grid > a.n_pix_tiles) grid = a.n_pix_tiles;
-#define QE_PWRP_LAUNCH(KSV, TWV)                                                                                           \
-    do {                                                                                                                    \
-        static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pwrp_kernel<7, KSV, TWV>),        \
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, PwrpGeom<7, KSV, TWV>::LDS) == hipSuccess; \
-        (void)ok_;                                                                                                          \
-        constexpr size_t lds_ = PwrpGeom<7, KSV, TWV>::LDS;                                                                 \
-        hipLaunchKernelGGL((conv_pwrp_kernel<7, KSV, TWV>), dim3((unsigned)grid), dim3(512), lds_, s, a);                   \
-    } while (0)
-        if (pl.tw == 224) { if (pl.ks == 2) QE_PWRP_LAUNCH(2, 224); else QE_PWRP_LAUNCH(4, 224); }
-        else { if (pl.ks == 2) QE_PWRP_LAUNCH(2, 196); else QE_PWRP_LAUNCH(4, 196); }
-#undef QE_PWRP_LAUNCH
-        QE_LAUNCH_CHECK();
-        return QE_OK;
-    }
 #define QE_PWR_LAUNCH2(WV, KSV, TWV, S2V, RQV)                                                                             \
     do {                                                                                                                    \
         static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pwr_kernel<7, WV, KSV, TWV, S2V, RQV>), \

@@ -29,8 +29,8 @@ SHAPES = [
     (2, 256, 56, 56, 128, 1, 1, 0),     # layer2.0.conv1
     (40, 64, 14, 14, 192, 1, 1, 0),     # more tiles than XCDs
     (1, 128, 28, 16, 128, 1, 1, 0),     # 448-pixel planes: 2 tiles of 224
-    (3, 128, 14, 14, 288, 1, 1, 0),     # persistent form, 9 strips on 8 waves (one wave reloads weights, seven keep theirs)
-    (5, 64, 28, 28, 512, 1, 1, 0),      # persistent form, 20 tiles, two strips per wave
+    (3, 128, 14, 14, 288, 1, 1, 0),     # 9 strips on 4 waves (uneven)
+    (5, 64, 28, 28, 512, 1, 1, 0),      # 20 tiles, four strips per wave
     (4, 512, 7, 7, 2048, 1, 1, 0),      # ResNet-50 layer4 expansion: 7x7 planes, 2 images per tile, the tensor's last byte patched
     (8, 512, 7, 7, 512, 1, 1, 0),       # 7x7, one channel group, two strips per wave
     (4, 256, 7, 7, 768, 1, 1, 0),       # 7x7, 4 images per tile, 3 strips per wave
@@ -52,18 +52,12 @@ def _with_env(env, fn):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("pwr", ["1", "0", "grid3", "persist"])
+@pytest.mark.parametrize("pwr", ["1", "0"])
 def test_pwr_vs_oracle(engine, pwr):
-    """pwr = 1: default routing (one tile per workgroup); persist: the opt-in persistent double-buffered form for IC <= 128 / OC >= 256;
-    grid3: that form on THREE workgroups, so each walks many tiles (tile switch, buffer swap, weight reload and the patched
+    """pwr = 1: every eligible layer on the resident-tile kernel (one tile per workgroup; the patched
     tail of the tensor in a late tile); 0: kernel disabled."""
     rng = np.random.RandomState(4242)
     env = {"QE_PWR": "0" if pwr == "0" else "2"}      # 2: every eligible layer (default 1 = whole-plane tiles only)
-    if pwr == "grid3":
-        env["QE_PWR_GRID"] = "3"
-        env["QE_PWR_PERSIST"] = "1"
-    if pwr == "persist":
-        env["QE_PWR_PERSIST"] = "1"
 
     def run():
         for shp in SHAPES:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-phase cycle breakdown of conv_pwr_kernel (one tile per workgroup) from the -DQE_STAMP diagnostic build.
-usage: QE_LIB=quantize_amd/_ext/libqe_hip_stamp.so QE_PWR_PERSIST=0 python tools/stamp_pwr.py [--batch N] 26 13 3"""
+usage: QE_LIB=quantize_amd/_ext/libqe_hip_stamp.so python tools/stamp_pwr.py [--batch N] 26 13 3"""
 import ctypes, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
