@@ -252,7 +252,10 @@ int qe_quantlinear(const qe_qparam *x, const qe_qparam *w, const float *bias,
 
 /* Replaces quantlinear_float_input (functions/quantlinear_float_input.cu:120-182, kernel :36-104):
  *   out[b, o] = bias[o] + sum_k x[b,k] * ((q_w[o,k] - zw[o]) * sw[o])      ((q - zero): :82-86)
- * x: B*K floats.  w->n_param is 1 (per tensor iff numel()==1, :170) or O.                              */
+ * x: B*K floats.  w->n_param is 1 (per tensor iff numel()==1, :170) or O.
+ * Non-finite activations (this entry point and qe_quantconv2d_float_input, on their MFMA kernels): every output that depends
+ * on a +-inf or NaN activation is non-finite -- NaN where the reference's fmaf chain may keep +-inf (the exact bf16 split of
+ * an infinity leaves inf - inf in the remainder terms) -- and every other output is unaffected.                          */
 int qe_quantlinear_float_input(const float *x, const qe_qparam *w, const float *bias,
                                int64_t B, int32_t K, int32_t O, float *out, qe_stream_t stream);
 

@@ -111,3 +111,53 @@ def test_env_switch_keeps_valu_kernel(engine):
             os.environ.pop("QE_F32_MFMA", None)
         else:
             os.environ["QE_F32_MFMA"] = old
+
+
+def test_non_finite_activations_declared_behaviour(engine):
+    """Declared in include/quant_engine.h: an output that depends on a non-finite activation (+-inf, NaN) is non-finite -- the
+    bf16 x 3 split turns +-inf into NaN in the remainder terms where the reference's fmaf chain may keep +-inf -- and every
+    other output is exactly what it is without that activation.  Checked on the MFMA kernels of quantconv2d_float_input
+    (3x3 with padding, 1x1) and of quantlinear_float_input."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    for (N, IC, H, OC, K, s, p) in [(2, 64, 14, 96, 3, 1, 1), (2, 128, 14, 64, 1, 1, 0)]:
+        x = torch.randn(N, IC, H, H, generator=g, device="cuda")
+        qw = torch.randint(-128, 128, (OC, IC, K, K), generator=g, device="cuda", dtype=torch.int16)
+        wp, wd = engine.tpack(qw, 8, True)
+        sw = (torch.rand(OC, generator=g, device="cuda") * 5e-4 + 2.5e-4).reshape(OC, 1, 1, 1)
+        zw = torch.zeros(OC, 1, 1, 1, device="cuda")
+        bad = [(0, 3, 5, 6, float("inf")), (1, 10, 0, 13, float("-inf")), (1, 20, 9, 2, float("nan"))]
+        xb, xc = x.clone(), x.clone()
+        for (n, c, h, w, v) in bad:
+            xb[n, c, h, w] = v
+            xc[n, c, h, w] = 0.0
+        yb = engine.quantconv2d_float_input(xb, wp, wd, sw, zw, None, s, p)
+        yc = engine.quantconv2d_float_input(xc, wp, wd, sw, zw, None, s, p)
+        OH = yb.shape[2]
+        hit = torch.zeros(N, OH, OH, dtype=torch.bool, device="cuda")
+        for (n, c, h, w, v) in bad:
+            for oh in range(OH):
+                for ow in range(OH):
+                    if 0 <= h - (oh * s - p) < K and 0 <= w - (ow * s - p) < K:
+                        hit[n, oh, ow] = True
+        hit = hit[:, None].expand_as(yb)
+        assert hit.any() and not torch.isfinite(yb[hit]).any(), (IC, K)
+        assert torch.isfinite(yb[~hit]).all() and torch.equal(yb[~hit], yc[~hit]), (IC, K)
+    # linear: a non-finite activation poisons its whole output row, nothing else
+    B, Kd, O = 130, 768, 256
+    x = torch.randn(B, Kd, generator=g, device="cuda")
+    qw = torch.randint(-128, 128, (O, Kd), generator=g, device="cuda", dtype=torch.int16)
+    wp, wd = engine.tpack(qw, 8, True)
+    sw = torch.rand(O, generator=g, device="cuda") * 5e-4 + 2.5e-4
+    zw = torch.zeros(O, device="cuda")
+    assert capi.linear_float_input_path(x, capi.qparam(wp, 8, 1, sw, zw), B, Kd, O) == 1
+    xb, xc = x.clone(), x.clone()
+    for (r, k, v) in [(3, 5, float("inf")), (77, 700, float("-inf")), (129, 31, float("nan"))]:
+        xb[r, k] = v
+        xc[r, k] = 0.0
+    yb = engine.quantlinear_float_input(xb, wp, wd, sw, zw, None)
+    yc = engine.quantlinear_float_input(xc, wp, wd, sw, zw, None)
+    rows = torch.zeros(B, dtype=torch.bool, device="cuda")
+    rows[[3, 77, 129]] = True
+    assert not torch.isfinite(yb[rows]).any()
+    assert torch.isfinite(yb[~rows]).all() and torch.equal(yb[~rows], yc[~rows])
