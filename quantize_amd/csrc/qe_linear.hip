@@ -296,39 +296,45 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a)
     const bool vec4 = (a.O & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
     float *patch = reinterpret_cast<float *>(lsm) + wave * (32 * 36);
     const int rrow = lane >> 3, rq = lane & 7;
+    // Two instances, the choice made once per workgroup: a (wave-uniform) bounds test per tile is a branch per tile, and hipcc
+    // opens every block behind a branch with s_waitcnt vmcnt(0) in kernels with LDS-DMA in a loop -- a drain of all outstanding
+    // stores in front of every tile (found in linear_mfma8_kernel's epilogue, see there).
+    auto tiles = [&](auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int cl = wn * 32 * NJ + j * 32 + col;
-        const int c = n0 + cl;
-        const float4 cc = colc[cl];                       // sw, zw', bias
-        const float sws = (float)(swa[j] + __shfl_xor(swa[j], 32));
+        for (int j = 0; j < NJ; ++j) {
+            const int cl = wn * 32 * NJ + j * 32 + col;
+            const int c = n0 + cl;
+            const float4 cc = colc[cl];                       // sw, zw', bias
+            const float sws = (float)(swa[j] + __shfl_xor(swa[j], 32));
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float v[16];
+            for (int i = 0; i < 2; ++i) {
+                float v[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float4 rc = rowc[rl];
-                float t = (float)acc[i][j][r];
-                t = fmaf(cc.y, rc.z, t);
-                t = fmaf(rc.y, sws, t);
-                t = fmaf(rc.w, cc.y, t);
-                v[r] = fmaf(rc.x * cc.x, t, cc.z);
-            }
-            if (vec4) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + col] = v[r];
-                __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): same wave wrote and reads
-                const int c4 = n0 + wn * 32 * NJ + j * 32 + 4 * rq;
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float4 rc = rowc[rl];
+                    float t = (float)acc[i][j][r];
+                    t = fmaf(cc.y, rc.z, t);
+                    t = fmaf(rc.y, sws, t);
+                    t = fmaf(rc.w, cc.y, t);
+                    v[r] = fmaf(rc.x * cc.x, t, cc.z);
+                }
                 const int64_t row0 = m0 + wm * 64 + i * 32;
-                if (row0 + 32 <= a.B && n0 + wn * 32 * NJ + j * 32 + 32 <= a.O) {   // wave-uniform: plain stores
+                if constexpr (FULL) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + col] = v[r];
+                    const int c4 = n0 + wn * 32 * NJ + j * 32 + 4 * rq;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int rt = 8 * k + rrow;
                         const float4 o4 = *reinterpret_cast<const float4 *>(patch + rt * 36 + 4 * rq);
                         *reinterpret_cast<float4 *>(a.out + (row0 + rt) * a.O + c4) = o4;
                     }
-                } else {
+                } else if (vec4) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + col] = v[r];
+                    const int c4 = n0 + wn * 32 * NJ + j * 32 + 4 * rq;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int rt = 8 * k + rrow;
@@ -336,17 +342,18 @@ __global__ __launch_bounds__(256, 2) void linear_mfma_kernel(const LinArgs a)
                         const int64_t row = row0 + rt;
                         if (row < a.B && c4 < a.O) *reinterpret_cast<float4 *>(a.out + row * a.O + c4) = o4;
                     }
-                }
-                __builtin_amdgcn_s_waitcnt(0xc07f);   // reads done before the next tile overwrites the patch
-            } else {
+                } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (row < a.B && c < a.O) a.out[row * a.O + c] = v[r];
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (row < a.B && c < a.O) a.out[row * a.O + c] = v[r];
+                    }
                 }
             }
         }
-    }
+    };
+    // (a wave's own LDS operations complete in order: its reads see its writes, a later tile's writes cannot overtake them)
+    if (vec4 && m0 + LM <= a.B && n0 + LN <= a.O) tiles(std::true_type{}); else tiles(std::false_type{});
 #ifdef QE_STAMP
     LIN_ST(6);   // epilogue issue
     __builtin_amdgcn_s_waitcnt(0x0f70);
@@ -887,8 +894,10 @@ extern "C" int qe_quantlinear(const qe_qparam *x, const qe_qparam *w, const floa
         int big = 0;
         if ((K % L8_K) == 0 && (O % L8_TN) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && B * (int64_t)K < (1ll << 32) &&
             (int64_t)O * K < (1ll << 32) && O < (1 << 28)) {
-            if (K > 1024 && (B / 320) * (O / L8_TN) >= kNumCU) big = 1;
-            else if (K <= 1024 && (B / 160) * (O / L8_TN) >= 2 * kNumCU) big = 2;
+            // thresholds from tools/bench_linear.py at 256 / 64 / 16 images (profiles/r03zz_lin_small_batches.txt): the big tiles
+            // still win at 12,608 rows (120 / 237 tiles), the 64-deep kernel's smaller tiles at 3,152 rows unless O is wide
+            if (K > 1024 && (B / 320) * (O / L8_TN) >= kNumCU / 3) big = 1;
+            else if (K <= 1024 && (B / 160) * (O / L8_TN) >= kNumCU / 2) big = 2;
             if (const char *e = env_get("QE_LIN8")) big = atoi(e);
             if (big < 0 || big > 2) big = 0;
         }
