@@ -6,7 +6,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "conv_mfma" not in k and "conv_flatd" not in k:
+        if "conv_mfma" not in k and "conv_flatd" not in k and "conv_pwr" not in k:
             continue
         key = (k[:70], r.get("Grid_Size", ""), r.get("LDS_Block_Size", ""))
         acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
