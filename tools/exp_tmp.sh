@@ -1,4 +1,5 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rm -rf gpurun_out/r03z
-bash tools/profile_round.sh r03z > gpurun_out/r03z_profile.log 2>&1; tail -2 gpurun_out/r03z_profile.log | cut -c1-300
-timeout -k 10 300 python bench.py > gpurun_out/r03z_bench.json 2> gpurun_out/r03z_bench.err; tail -c 500 gpurun_out/r03z_bench.json
+timeout -k 10 900 python -m pytest tests/test_conv_gpu.py tests/test_conv_fuzz_gpu.py tests/test_prepared_gpu.py -x -q > gpurun_out/r03zz_stem_test.txt 2>&1; echo "rc=$?"; tail -3 gpurun_out/r03zz_stem_test.txt
+AB_EXTRA="--cold --layers 0" bash tools/ab_env.sh QE_STEM_SWAP 0 1 0 1 2>&1 | tail -4
+grep -E "^ *0 conv1" gpurun_out/ab_QE_STEM_SWAP_0.err gpurun_out/ab_QE_STEM_SWAP_1.err
+for v in 0 1 0 1; do QE_STEM_SWAP=$v timeout -k 10 200 python bench.py --steps 200 --warmup 5 --no-cpu-baseline 2>/dev/null > gpurun_out/r03zz_stem_$v.json; python -c "
+import json;j=json.load(open('gpurun_out/r03zz_stem_$v.json'));print('QE_STEM_SWAP=$v', round(j['value']), round(j['roofline']['conv_stack_ms'],4))"; done | tee gpurun_out/r03zz_ab_stem_swap.txt
