@@ -172,7 +172,7 @@ def test_float_input_mfma_vit_shapes(engine, monkeypatch):
         y, path = _run(engine, c, True)
         assert path == 2
         err = np.abs(y.cpu().numpy().astype(np.float64) - c["o64"]).max()
-        assert err <= max(1e-5, 2.0 * np.abs(c["o32"].astype(np.float64) - c["o64"]).max()), (B, K, O, err)
+        assert err <= max(1e-5, np.abs(c["o32"].astype(np.float64) - c["o64"]).max()), (B, K, O, err)   # the conv rule: no headroom factor
     monkeypatch.setenv("QE_LIN_F32_MFMA", "0")
     capi.reload_env()
     y0, path0 = _run(engine, c, True)
