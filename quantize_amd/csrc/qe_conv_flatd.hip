@@ -41,6 +41,12 @@ struct FlatdArgs {
     int N, IC, OC, P;
     int tiles_per_image;       // WIDE: pixel tiles per plane; SMALL: unused
     int n_pix_tiles, n_oc_tiles, chunk;
+    // fused re-quantisation (7x7 planes, RQ instances): the 8-bit code of the consumer's quantiser instead of fp32, fields as in MfmaArgs
+    uint8_t *rq_out;
+    const float *rq_scale, *rq_zero;
+    float rq_qmin, rq_qmax, rq_lo, rq_hi;
+    unsigned rq_offset;
+    int32_t *rq_status;
 };
 
 constexpr int FD_CK = 64;              // channels per stage
@@ -166,7 +172,7 @@ __device__ __forceinline__ void fd_wait_vmcnt(int n)   // n wave-uniform, 0..31
 #undef QE_VMW
 }
 
-template <int NT, bool SMALL, int FD_RING, int WAVES>
+template <int NT, bool SMALL, int FD_RING, int WAVES, bool RQ = false>
 __global__ __launch_bounds__(64 * WAVES, 2) void conv_flatd_kernel(const FlatdArgs a)
 {
     using G = FdGeom<NT, SMALL, FD_RING, WAVES>;
@@ -415,6 +421,56 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv_flatd_kernel(const FlatdAr
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
         }
+    } else if constexpr (RQ) {
+        // fused re-quantisation: a wave's 32 channels x 49 codes of one image are ONE contiguous 1,568-byte run of the output
+        // (16-byte aligned: oc0 % 32 == 0 and OC % 32 == 0, host) -- laid out in the patch as in memory, copied flat.  The
+        // fp32 value is computed exactly as below, then quantised as quantize_pack would (rq_value / rq_fast2).
+        static_assert(SMALL, "re-quantising instances exist for the 7x7 form only");
+        uint8_t *bp = smem + wave * (32 * 49 * 4);
+        const int oc0 = ot * FD_MT + wave * 32;
+        RqConst rqc = rq_setup(a);
+        rqc.slow = __builtin_amdgcn_readfirstlane(rqc.slow);
+        rqc.chk = __builtin_amdgcn_readfirstlane(rqc.chk);
+        bool bad = false;
+        const bool fast = rq_fast_ok(rqc) && __builtin_amdgcn_ballot_w64(!rq_bounded(alpha, cst, bia, zwp)) == 0ull;
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+            const bool img = n0 + gi < a.N;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int pxl = 32 * tt + (r & 3) + 8 * (r >> 2) + 4 * h;      // r even: pxl, pxl + 1 are registers r, r + 1
+                    float f0 = (float)acc[2 * gi + tt][r] + cst, f1 = (float)acc[2 * gi + tt][r + 1] + cst;
+                    if (need_sx) {
+                        f0 = fmaf(-zwp, (float)sxp[64 * gi + pxl], f0);
+                        f1 = fmaf(-zwp, (float)sxp[64 * gi + pxl + 1], f1);
+                    }
+                    const float y0 = fmaf(alpha, f0, bia), y1 = fmaf(alpha, f1, bia);
+                    float c0, c1;
+                    if (fast) {
+                        const v2f c2 = rq_fast2(rqc, v2f{y0, y1});
+                        c0 = c2.x; c1 = c2.y;
+                    } else {
+                        bool b0 = false, b1 = false;
+                        c0 = rq_value(rqc, y0, b0);
+                        c1 = rq_value(rqc, y1, b1);
+                        bad |= img && oc < a.OC && ((b0 && pxl < P) || (b1 && pxl + 1 < P));
+                    }
+                    if (pxl < P) bp[col * P + pxl] = (uint8_t)(unsigned)c0;
+                    if (pxl + 1 < P) bp[col * P + pxl + 1] = (uint8_t)(unsigned)c1;
+                }
+            }
+            if (img && oc0 + 32 <= a.OC) {
+                uint8_t *dst = a.rq_out + ((int64_t)(n0 + gi) * a.OC + oc0) * P;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const uint4 d4 = *reinterpret_cast<const uint4 *>(bp + 16 * (64 * k + lane));
+                    if (64 * k + lane < 98) *reinterpret_cast<uint4 *>(dst + 16 * (64 * k + lane)) = d4;
+                }
+            }
+        }
+        rq_report(a, bad);
     } else {
         // a wave's 32 channels x P pixels of one image are ONE contiguous, 16-byte aligned run of the output
         // ((n OC + oc0) P floats, oc0 % 32 == 0, OC % 4 == 0): the patch is laid out exactly like it and copied flat.
@@ -467,12 +523,28 @@ int flatd_variant(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *
     return waste(5) < waste(7) - 0.03 ? 5 : 7;
 }
 
+// rq != nullptr: the re-quantising instances (7x7 planes, whole 32-channel strips: OC % 32 == 0, 8-bit codes, one scale)
+bool flatd_requant_ok(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w, const RequantHost *rq)
+{
+    return rq != nullptr && flatd_variant(sh, x, w) == 8 && sh->OC % 32 == 0 && rq->n_bits == 8 && rq->n_param == 1 && rq->out != nullptr &&
+           (reinterpret_cast<uintptr_t>(rq->out) & 15) == 0 && !(env_get("QE_FLATD_RQ") && atoi(env_get("QE_FLATD_RQ")) == 0);
+}
+
 int launch_flatd(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh, float *out,
-                 hipStream_t s)
+                 hipStream_t s, const RequantHost *rq)
 {
     const int var = flatd_variant(sh, x, w);
     if (var == 0) return QE_ERR_UNSUPPORTED;
+    if (rq != nullptr && !flatd_requant_ok(sh, x, w, rq)) return QE_ERR_UNSUPPORTED;
     FlatdArgs a;
+    a.rq_out = nullptr; a.rq_scale = nullptr; a.rq_zero = nullptr; a.rq_status = nullptr;
+    a.rq_qmin = a.rq_qmax = a.rq_lo = a.rq_hi = 0.0f; a.rq_offset = 0;
+    if (rq != nullptr) {
+        a.rq_out = rq->out; a.rq_scale = rq->scale; a.rq_zero = rq->zero;
+        a.rq_qmin = rq->qmin; a.rq_qmax = rq->qmax; a.rq_status = rq->status;
+        a.rq_offset = rq->sign ? 128u : 0u;                       // tpack.cu:108-111
+        a.rq_lo = rq->sign ? -128.0f : 0.0f; a.rq_hi = rq->sign ? 127.0f : 255.0f;
+    }
     a.x = static_cast<const uint8_t *>(x->data); a.w = static_cast<const uint8_t *>(w->data);
     a.x_scale = x->scale; a.x_zero = x->zero; a.w_scale = w->scale; a.w_zero = w->zero; a.bias = bias;
     a.x_sign = x->sign; a.w_sign = w->sign; a.w_per_tensor = (w->n_param == 1);
@@ -505,7 +577,18 @@ int launch_flatd(const qe_qparam *x, const qe_qparam *w, const float *bias, cons
         constexpr size_t lds_ = FdGeom<NTV, SM, RG, WV>::LDS;                                                               \
         hipLaunchKernelGGL((conv_flatd_kernel<NTV, SM, RG, WV>), dim3((unsigned)blocks), dim3(64 * WV), lds_, s, a);        \
     } while (0)
-    if (w8) {
+    if (rq != nullptr) {
+#define QE_FD_LAUNCH_RQ(WV)                                                                                                 \
+    do {                                                                                                                    \
+        static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_flatd_kernel<8, true, 3, WV, true>), \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, FdGeom<8, true, 3, WV>::LDS) == hipSuccess; \
+        (void)ok_;                                                                                                          \
+        constexpr size_t lds_ = FdGeom<8, true, 3, WV>::LDS;                                                                \
+        hipLaunchKernelGGL((conv_flatd_kernel<8, true, 3, WV, true>), dim3((unsigned)blocks), dim3(64 * WV), lds_, s, a);   \
+    } while (0)
+        if (w8) QE_FD_LAUNCH_RQ(8); else QE_FD_LAUNCH_RQ(4);
+#undef QE_FD_LAUNCH_RQ
+    } else if (w8) {
         if (var == 8) QE_FD_LAUNCH(8, true, 3, 8); else if (var == 5) QE_FD_LAUNCH(5, false, 3, 8); else QE_FD_LAUNCH(7, false, 3, 8);
     } else {
         if (var == 8) QE_FD_LAUNCH(8, true, 3, 4); else if (var == 5) QE_FD_LAUNCH(5, false, 3, 4); else QE_FD_LAUNCH(7, false, 3, 4);

@@ -651,7 +651,9 @@ unsigned long long *g_mfma_dbg = nullptr;   // also read by qe_linear.hip (diagn
 
 int expand_codes_s8(const uint8_t *packed, int64_t n, int n_bits, int sign, uint8_t *out, hipStream_t s);   // qe_tpack.hip
 int flatd_variant(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w);                          // qe_conv_flatd.hip
-int launch_flatd(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh, float *out, hipStream_t s);
+int launch_flatd(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh, float *out, hipStream_t s,
+                 const RequantHost *rq = nullptr);
+bool flatd_requant_ok(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w, const RequantHost *rq);
 bool pwr_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w, const RequantHost *rq);  // qe_conv_pwr.hip
 int launch_pwr(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh, float *out, hipStream_t s,
                const RequantHost *rq);
@@ -830,7 +832,7 @@ int launch_conv_mfma(const qe_qparam *x, const qe_qparam *w, const float *bias, 
         const char *e = env_get("QE_FLATD");
         const int mask = e ? atoi(e) : QE_FLATD_DEFAULT;
         const int bit = var == 7 ? 1 : (var == 5 ? 2 : (var == 8 ? 4 : 0));
-        if (var != 0 && (mask & bit) && rq == nullptr) return mode == 1 ? QE_OK : launch_flatd(x, w, bias, sh, out, s);
+        if (var != 0 && (mask & bit) && (rq == nullptr || flatd_requant_ok(sh, x, w, rq))) return mode == 1 ? QE_OK : launch_flatd(x, w, bias, sh, out, s, rq);
     }
 
     PrepArgs pa;

@@ -511,7 +511,10 @@ template <int KS, int GI> struct Pwr7Geom {
     static constexpr int LDS = XBYTES + TAB + WAVES * PATCH;
 };
 
-template <int KS, int GI>
+// RQ: fused re-quantisation (qe_quantconv2d_requant_prepared): the strip's 32 planes x 49 codes of an image are ONE contiguous,
+// 16-byte aligned 1,568-byte run of the output; the wave lays the codes out in its patch as they stand in memory (byte writes)
+// and copies the run flat: 2 store instructions per image and strip instead of 7.
+template <int KS, int GI, bool RQ = false>
 __global__ __launch_bounds__(512, 2) void conv_pwr7_kernel(const PwrArgs a)
 {
     using G = Pwr7Geom<KS, GI>;
@@ -655,8 +658,17 @@ __global__ __launch_bounds__(512, 2) void conv_pwr7_kernel(const PwrArgs a)
         }
     };
 
+    RqConst rqc;
+    bool bad = false, rq_fast_u = false;
+    if constexpr (RQ) {
+        rqc = rq_setup(a);
+        rqc.slow = __builtin_amdgcn_readfirstlane(rqc.slow);
+        rqc.chk = __builtin_amdgcn_readfirstlane(rqc.chk);
+        rq_fast_u = rq_fast_ok(rqc);
+    }
     auto epilogue = [&](int strip, float e_sw, float e_zw, float e_bi, bool need_sx) __attribute__((always_inline)) {
         const int oc0 = strip * 32;
+        bool fast = false;
         {
             const float zwp = e_zw - zw_shift;
             const int sw_sum = swacc + __shfl_xor(swacc, 32);
@@ -667,6 +679,66 @@ __global__ __launch_bounds__(512, 2) void conv_pwr7_kernel(const PwrArgs a)
                 tab[64 + col] = e_bi;
                 tab[96 + col] = zwp;
             }
+            if constexpr (RQ) fast = rq_fast_u && __builtin_amdgcn_ballot_w64(!rq_bounded(sx * e_sw, cst, e_bi, zwp)) == 0ull;
+        }
+        if constexpr (RQ) {
+            uint8_t *bp = reinterpret_cast<uint8_t *>(patch);                  // [32][49] codes of one image, as in memory
+#pragma unroll
+            for (int gi = 0; gi < GI; ++gi) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 al = *reinterpret_cast<const float4 *>(tab + 8 * gq + 4 * h);
+                    const float4 cs = *reinterpret_cast<const float4 *>(tab + 32 + 8 * gq + 4 * h);
+                    const float4 bi = *reinterpret_cast<const float4 *>(tab + 64 + 8 * gq + 4 * h);
+                    const float alv[4] = {al.x, al.y, al.z, al.w}, csv[4] = {cs.x, cs.y, cs.z, cs.w};
+                    const float biv[4] = {bi.x, bi.y, bi.z, bi.w};
+                    float zwv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (need_sx) {
+                        const float4 zw = *reinterpret_cast<const float4 *>(tab + 96 + 8 * gq + 4 * h);
+                        zwv[0] = zw.x; zwv[1] = zw.y; zwv[2] = zw.z; zwv[3] = zw.w;
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int t = 2 * gi + tt;
+                        const int px = 32 * tt + col;
+                        const bool real = tt == 0 || px < P;
+                        float y[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            // the fp32 form's operation order, then quantised as quantize_pack would
+                            float f = (float)acc[t][4 * gq + j] + csv[j];
+                            if (need_sx) f = fmaf(-zwv[j], sxv[t], f);
+                            y[j] = fmaf(alv[j], f, biv[j]);
+                        }
+                        if (fast) {
+#pragma unroll
+                            for (int j = 0; j < 4; j += 2) {
+                                const v2f c2 = rq_fast2(rqc, v2f{y[j], y[j + 1]});
+                                if (real) {
+                                    bp[(8 * gq + 4 * h + j) * P + px] = (uint8_t)(unsigned)c2.x;
+                                    bp[(8 * gq + 4 * h + j + 1) * P + px] = (uint8_t)(unsigned)c2.y;
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                bool b = false;
+                                const float r = rq_value(rqc, y[j], b);
+                                bad |= b && real;
+                                if (real) bp[(8 * gq + 4 * h + j) * P + px] = (uint8_t)(unsigned)r;
+                            }
+                        }
+                    }
+                }
+                // the run of image n0 + gi: 32 x 49 codes = 98 16-byte pieces, copied flat
+                uint8_t *dst = a.rq_out + ((int64_t)(n0 + gi) * a.OC + oc0) * P;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const uint4 d4 = *reinterpret_cast<const uint4 *>(bp + 16 * (64 * k + lane));
+                    if (64 * k + lane < 98) *reinterpret_cast<uint4 *>(dst + 16 * (64 * k + lane)) = d4;
+                }
+            }
+            return;
         }
 #pragma unroll
         for (int gi = 0; gi < GI; ++gi) {
@@ -712,11 +784,12 @@ __global__ __launch_bounds__(512, 2) void conv_pwr7_kernel(const PwrArgs a)
         const float e_sw = c_sw, e_zw = c_zw, e_bi = c_bi;
         load_w(strip0 + (s + 1) * WAVES);
         epilogue(strip0 + s * WAVES, e_sw, e_zw, e_bi, sx_cur);
-        QE_PWR7_WAIT(NRB * GI);                               // the strip's stores stay in flight
+        QE_PWR7_WAIT((RQ ? 2 : NRB) * GI);                    // the strip's stores stay in flight
         sx_cur = __builtin_amdgcn_ballot_w64((c_zw - zw_shift) != 0.0f) != 0ull;
         if (sx_cur) mma_strip(std::true_type{}); else mma_strip(std::false_type{});
     }
     epilogue(strip0 + (n_my - 1) * WAVES, c_sw, c_zw, c_bi, sx_cur);
+    if constexpr (RQ) rq_report(a, bad);
 #undef QE_PWR7_WAIT
 }
 
@@ -789,8 +862,7 @@ static int pwr7_plan(const qe_conv_shape *sh, const qe_qparam *x, const qe_qpara
     return gi;
 }
 
-// rq != nullptr: the fused re-quantising form (8-bit codes, one scale: what the kernels' epilogue covers); the 7x7 and the
-// kernel has none
+// rq != nullptr: the fused re-quantising form (8-bit codes, one scale: what the kernels' epilogue covers)
 bool pwr_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *w, const RequantHost *rq)
 {
     PwrPlan pl;
@@ -798,17 +870,28 @@ bool pwr_eligible(const qe_conv_shape *sh, const qe_qparam *x, const qe_qparam *
     if (rq != nullptr) {
         if (rq->n_bits != 8 || rq->n_param != 1 || rq->out == nullptr || (reinterpret_cast<uintptr_t>(rq->out) & 15) != 0) return false;
         if (env_get("QE_PWR_RQ") && atoi(env_get("QE_PWR_RQ")) == 0) return false;
-        return pwr_plan(sh, x, w, &pl);
+        return pwr_plan(sh, x, w, &pl) || pwr7_plan(sh, x, w, &g) != 0;
     }
     return pwr_plan(sh, x, w, &pl) || pwr7_plan(sh, x, w, &g) != 0;
 }
 
-static int launch_pwr7(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh, float *out, hipStream_t s)
+static int launch_pwr7(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh, float *out, hipStream_t s,
+                       const RequantHost *rq)
 {
     int groups = 1;
     const int gi = pwr7_plan(sh, x, w, &groups);
-    if (gi == 0 || (reinterpret_cast<uintptr_t>(out) & 15) != 0) return QE_ERR_UNSUPPORTED;
+    if (gi == 0 || (rq == nullptr && (reinterpret_cast<uintptr_t>(out) & 15) != 0)) return QE_ERR_UNSUPPORTED;
     PwrArgs a;
+    a.rq_out = nullptr; a.rq_scale = nullptr; a.rq_zero = nullptr; a.rq_status = nullptr;
+    a.rq_qmin = a.rq_qmax = a.rq_lo = a.rq_hi = 0.0f; a.rq_offset = 0;
+    if (rq != nullptr) {
+        if (!pwr_eligible(sh, x, w, rq)) return QE_ERR_UNSUPPORTED;
+        a.rq_out = rq->out; a.rq_scale = rq->scale; a.rq_zero = rq->zero;
+        a.rq_qmin = rq->qmin; a.rq_qmax = rq->qmax; a.rq_status = rq->status;
+        a.rq_offset = rq->sign ? 128u : 0u;                       // tpack.cu:108-111
+        a.rq_lo = rq->sign ? -128.0f : 0.0f; a.rq_hi = rq->sign ? 127.0f : 255.0f;
+    }
+    a.W_in = 7; a.PIN = 49; a.OW = 7;
     a.x = static_cast<const uint8_t *>(x->data); a.w = static_cast<const uint8_t *>(w->data);
     a.x_scale = x->scale; a.x_zero = x->zero; a.w_scale = w->scale; a.w_zero = w->zero; a.bias = bias;
     a.x_sign = x->sign; a.w_sign = w->sign; a.w_per_tensor = (w->n_param == 1);
@@ -823,16 +906,18 @@ static int launch_pwr7(const qe_qparam *x, const qe_qparam *w, const float *bias
     const int64_t runs = ((int64_t)a.n_pix_tiles + a.chunk - 1) / a.chunk;
     const int64_t blocks = (runs + 7) / 8 * a.chunk * 8 * a.n_groups;
     if (blocks > 0x7fffffffLL) return QE_ERR_UNSUPPORTED;
-#define QE_PWR7_LAUNCH(KSV, GIV)                                                                                            \
+#define QE_PWR7_LAUNCH2(KSV, GIV, RQV)                                                                                      \
     do {                                                                                                                    \
-        static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pwr7_kernel<KSV, GIV>),           \
+        static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pwr7_kernel<KSV, GIV, RQV>),      \
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Pwr7Geom<KSV, GIV>::LDS) == hipSuccess; \
         (void)ok_;                                                                                                          \
         constexpr size_t lds_ = Pwr7Geom<KSV, GIV>::LDS;                                                                    \
-        hipLaunchKernelGGL((conv_pwr7_kernel<KSV, GIV>), dim3((unsigned)blocks), dim3(512), lds_, s, a);                    \
+        hipLaunchKernelGGL((conv_pwr7_kernel<KSV, GIV, RQV>), dim3((unsigned)blocks), dim3(512), lds_, s, a);               \
     } while (0)
+#define QE_PWR7_LAUNCH(KSV, GIV) do { if (rq != nullptr) QE_PWR7_LAUNCH2(KSV, GIV, true); else QE_PWR7_LAUNCH2(KSV, GIV, false); } while (0)
     if (sh->IC == 512) QE_PWR7_LAUNCH(16, 2); else if (sh->IC == 256) QE_PWR7_LAUNCH(8, 4); else QE_PWR7_LAUNCH(4, 4);
 #undef QE_PWR7_LAUNCH
+#undef QE_PWR7_LAUNCH2
     QE_LAUNCH_CHECK();
     return QE_OK;
 }
@@ -840,7 +925,7 @@ static int launch_pwr7(const qe_qparam *x, const qe_qparam *w, const float *bias
 int launch_pwr(const qe_qparam *x, const qe_qparam *w, const float *bias, const qe_conv_shape *sh, float *out, hipStream_t s,
                const RequantHost *rq)
 {
-    if (sh->H * sh->W == 49) return rq != nullptr ? QE_ERR_UNSUPPORTED : launch_pwr7(x, w, bias, sh, out, s);
+    if (sh->H * sh->W == 49) return launch_pwr7(x, w, bias, sh, out, s, rq);
     PwrPlan pl;
     if (!pwr_plan(sh, x, w, &pl)) return QE_ERR_UNSUPPORTED;
     PwrArgs a;

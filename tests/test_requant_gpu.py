@@ -36,6 +36,9 @@ SHAPES = [
     (2, 64, 28, 64, 256, 1, 2, 0),      # stride 2, 224-byte row pieces
     (40, 64, 14, 14, 192, 1, 1, 0),     # whole-plane tiles: a strip's 32 planes are one 6272-byte run; more tiles than XCDs
     (3, 128, 14, 14, 160, 1, 1, 0),     # 5 strips on 4 waves
+    (4, 512, 7, 7, 2048, 1, 1, 0),      # the 7x7-plane form: a strip's 32 planes x 49 codes of an image are one 1568-byte run
+    (8, 256, 7, 7, 768, 1, 1, 0),       # 4 images per tile, 3 strips per wave
+    (8, 128, 7, 7, 1024, 1, 1, 0),
 ]
 
 
